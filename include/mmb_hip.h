@@ -1,0 +1,223 @@
+/*
+ * mmb_hip.h -- C ABI of libmmb_hip.so: the MI355X (gfx950) hot path of hybrid
+ * continuous/discrete bridge matching (reference: dfaroughy/Multimodal-Bridges).
+ *
+ * The reference has no FFI: its pluggable boundary is Python duck typing through the
+ * registry dicts (pipeline/registry.py:9-55).  Each entry point below therefore cites the
+ * reference METHOD whose arithmetic it replaces; the Python classes of the same names in
+ * multimodal-bridges_amd/ bind these symbols through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - tensors are dense row-major: continuous (B,N,Dc) f32, discrete (B,N) int64
+ *     (the reference's (B,N,1) int64 viewed flat), per-jet vectors (B) f32;
+ *   - maskf is the canonical f32 0/1 mask (B,N) produced by mmb_mask_prepare;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it, nothing syncs,
+ *     nothing allocates (workspaces are caller-provided);
+ *   - return 0 on success, <0 on error (MMB_ERR_*); mmb_last_error() gives the message of
+ *     the calling thread's last failure.  Invalid arguments never launch a kernel.
+ *   - RNG: counter-based Philox4x32-10, key = seed, counter = (element index, offset);
+ *     the same (seed, offset) reproduces the same draws bit for bit.
+ */
+#ifndef MMB_HIP_H
+#define MMB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMB_OK 0
+#define MMB_ERR_INVALID_ARG (-1)
+#define MMB_ERR_LAUNCH (-2)
+#define MMB_ERR_UNSUPPORTED (-3)
+
+/* thermostat schedules, model/thermostats.py:24-52 */
+#define MMB_THERMO_CONSTANT 0
+#define MMB_THERMO_INVERSE 1
+#define MMB_THERMO_LINEAR 2
+#define MMB_THERMO_INVERSE_SQUARE 3
+#define MMB_THERMO_SIGMOID 4
+
+/* continuous bridges, model/bridges.py:8-40 (UniformFlow) and :74-108 (SchrodingerBridge) */
+#define MMB_BRIDGE_UNIFORM_FLOW 0
+#define MMB_BRIDGE_SCHRODINGER 1
+
+/* activations used by the EPiC layers */
+#define MMB_ACT_NONE 0
+#define MMB_ACT_GELU 1   /* exact erf form, nn.GELU() default  (epic.py:124) */
+#define MMB_ACT_LRELU 2  /* leaky_relu slope 0.01              (epic.py:172) */
+
+/* segment kinds of a concatenated linear input (mmb_linear_cat) */
+#define MMB_SEG_ROW 0       /* (M,K_s) one row per particle                              */
+#define MMB_SEG_JET 1       /* (B,K_s) one row per jet, broadcast over its N particles    */
+#define MMB_SEG_JET_MASK 2  /* (B,K_s) per jet, multiplied by maskf of the particle       */
+
+const char* mmb_last_error(void);
+int mmb_version(void);
+
+/* ---------------------------------------------------------------- masks / source ---- */
+
+/* Canonical mask: maskf = (mask != 0) as f32, counts[b] = sum_n maskf, total[0] = sum.
+ * Replaces the implicit `mask.sum()` / `mask.sum(1)` of multimodal_bridge_matching.py:180,190
+ * and epic.py:105.  mask_is_i64: 1 -> int64 input (aoj.py:160, noise.py:226), 0 -> f32. */
+int mmb_mask_prepare(int B, int N, const void* mask, int mask_is_i64,
+                     float* maskf, int32_t* counts, int32_t* total, void* stream);
+
+/* SourceUniform.__call__ (distributions/noise.py:212-243) on device with Philox:
+ * x0 ~ N(0,1) (B,N,Dc) [NULL to skip], k0 ~ U{0..V-1} (B,N) int64 [NULL to skip],
+ * mask: all ones, or (sample_masks) n ~ Categorical(pmf[0..n_pmf-1]) then ones in
+ * min(n,N) uniformly random slots (noise.py:215-226).  pmf is a device array of n_pmf
+ * floats (need not be normalised).  mask_i64 (B,N) and/or maskf (B,N) may be NULL. */
+int mmb_source_uniform(int B, int N, int Dc, int V, int sample_masks,
+                       const float* pmf, int n_pmf, uint64_t seed, uint64_t offset,
+                       float* x0, int64_t* k0, int64_t* mask_i64, float* maskf,
+                       int32_t* counts, void* stream);
+
+/* ---------------------------------------------------------------- K-A bridge sampling */
+
+/* sample_bridges (multimodal_bridge_matching.py:194-225) with INJECTED noise:
+ *   t[b]  = eps + (1-eps)*t_u[b]                                         (:202)
+ *   x_t   = t*x1 + (1-t)*x0 + std*z, std = sigma (UniformFlow, bridges.py:22-28)
+ *           or sigma*sqrt(t(1-t)) (SchrodingerBridge, bridges.py:87-93)
+ *   k_t   = inverse-CDF draw with uniform u from the telegraph bridge posterior
+ *           p(v) = p(v->k1;t,1) p(k0->v;0,t) / p(k0->k1;0,1)   (bridges.py:124-135,165-213)
+ * Continuous part is skipped when x0 == NULL, discrete part when k0 == NULL. */
+int mmb_bridge_sample(int B, int N, int Dc, int V,
+                      const float* t_u, float eps,
+                      const float* x0, const float* x1, const float* z,
+                      const int64_t* k0, const int64_t* k1, const float* u,
+                      int bridge_kind, float sigma, int thermo_kind, float gamma,
+                      float* t_out, float* xt, int64_t* kt, void* stream);
+
+/* Same, fused-RNG mode (training): draws t, the SourceUniform source (x0,k0), z and u from
+ * Philox in registers.  Reads x1,k1; writes t_out (B), x0_out (kept for the drift target
+ * x1-x0), xt, kt.  60 B/particle algorithmic. */
+int mmb_bridge_sample_rng(int B, int N, int Dc, int V, float eps,
+                          const float* x1, const int64_t* k1,
+                          int bridge_kind, float sigma, int thermo_kind, float gamma,
+                          uint64_t seed, uint64_t offset,
+                          float* t_out, float* x0_out, int64_t* k0_out, float* xt, int64_t* kt,
+                          void* stream);
+
+/* TelegraphBridge.transition_probability (bridges.py:165-191): probs (B,N,V), unnormalised */
+int mmb_telegraph_probs(int B, int N, int V, const float* t, const int64_t* k0, const int64_t* k1,
+                        int thermo_kind, float gamma, float* probs, void* stream);
+
+/* bridge drift targets: UniformFlow.drift (bridges.py:30-37) / SchrodingerBridge.drift (:95-103) */
+int mmb_bridge_drift(int B, int N, int Dc, const float* t, const float* xt, const float* x0,
+                     const float* x1, int bridge_kind, float* out, void* stream);
+
+/* ---------------------------------------------------------------- K-B continuous solver */
+
+/* ContinuousSolver.euler_step (solvers.py:21-25): x += dt*v, in place, n = B*N*Dc floats */
+int mmb_euler_step(int64_t n, float* x, const float* v, float dt, void* stream);
+
+/* ContinuousSolver.euler_maruyama_step (solvers.py:27-33): x += dt*v + sigma_t*dW with
+ * sigma_t = sigma*sqrt(t(1-t)) (bridges.py:105-108) -- NO sqrt(dt) factor, as the reference.
+ * t: per-jet (B) or NULL -> t_scalar.  dW injected (B,N,Dc) or NULL -> Philox(seed,offset). */
+int mmb_euler_maruyama_step(int B, int N, int Dc, float* x, const float* v, float dt,
+                            const float* t, float t_scalar, float sigma,
+                            const float* dW, uint64_t seed, uint64_t offset, void* stream);
+
+/* ---------------------------------------------------------------- K-C jump solver ------ */
+
+/* TelegraphBridge.rate (bridges.py:137-163): rates (B,N,V) = 1 + (wV/(1-w)) softmax(logits) + w q_k */
+int mmb_telegraph_rate(int B, int N, int V, const float* logits, const int64_t* k,
+                       const float* t, float t_scalar, int thermo_kind, float gamma,
+                       float* rates, void* stream);
+
+/* DiscreteSolver.tauleap_step (solvers.py:59-87) fused with rate():
+ *   delta_n != NULL : injected Poisson counts (B,N,V) f32 (parity mode), bit-exact k
+ *   delta_n == NULL : Philox mode; samples the only events that matter ({no jump},
+ *                     {exactly one jump, to v}) directly -- distribution-equivalent.
+ *   overflow_clamp  : 0 = "wrap" (default, :78-81), 1 = "clamp" (:83-87)
+ *   final_argmax    : 1 on the LAST grid point: k = argmax_v rates, as
+ *                     multimodal_bridge_matching.py:253-255 (the jump is discarded)
+ *   rates_out       : optional (B,N,V) store of the rates
+ * k is updated in place (padded slots too, quirk K3). */
+int mmb_rate_tauleap(int B, int N, int V, const float* logits, int64_t* k,
+                     const float* t, float t_scalar, float dt, int thermo_kind, float gamma,
+                     const float* delta_n, uint64_t seed, uint64_t offset,
+                     int overflow_clamp, int final_argmax, float* rates_out, void* stream);
+
+/* DiscreteSolver.euler_step (solvers.py:89-109) fused with rate(); u injected (B,N) or NULL -> Philox */
+int mmb_rate_euler_jump(int B, int N, int V, const float* logits, int64_t* k,
+                        const float* t, float t_scalar, float dt, int thermo_kind, float gamma,
+                        const float* u, uint64_t seed, uint64_t offset,
+                        int final_argmax, float* rates_out, void* stream);
+
+/* ---------------------------------------------------------------- K-F loss ------------ */
+
+#define MMB_LOSS_MAX_BLOCKS 1024
+/* loss_fn (multimodal_bridge_matching.py:165-192) forward + gradient w.r.t. the heads in
+ * one pass.  head_c (B,N,Dc) | NULL, head_d (B,N,V) | NULL.  The drift target is formed on
+ * the fly from (t, xt, x0, x1) (bridges.py:30-37 / :95-103).  vocab_freq (V) | NULL.
+ * coef (2): dLoss/dL_c, dLoss/dL_d (MultiModeLoss weights).  total: sum(mask) (int32).
+ * partials: workspace of 2*MMB_LOSS_MAX_BLOCKS floats.  Outputs: losses (2) = L_c, L_d;
+ * d_head_c, d_head_d (same shapes as the heads, may be NULL to skip the gradient). */
+int mmb_loss_fwd_bwd(int B, int N, int Dc, int V,
+                     const float* head_c, const float* head_d,
+                     const float* t, const float* xt, const float* x0, const float* x1, int bridge_kind,
+                     const int64_t* k1, const float* maskf, const int32_t* total,
+                     const float* vocab_freq, const float* coef,
+                     float* partials, float* losses, float* d_head_c, float* d_head_d, void* stream);
+
+/* MultiModeLoss (multimodal_bridge_matching.py:268-306): learnable (s != NULL):
+ * loss = sum_i 0.5*exp(-s_i)*L_i + 0.5*s_i ; fixed: sum_i w_i*L_i.
+ * coef_out (2) = dLoss/dL_i ; d_s (2) | NULL = dLoss/ds_i. */
+int mmb_multimode_coef(const float* s, const float* fixed_w_host2, float* coef_out, void* stream);
+int mmb_multimode_loss(const float* losses, const float* s, const float* fixed_w_host2,
+                       float* loss_out, float* d_s, void* stream);
+
+/* ---------------------------------------------------------------- K-D/K-E encoder ----- */
+
+/* weight_norm (old API, dim=0; epic.py:4, K5): W[o,:] = g[o] * v[o,:] / ||v[o,:]||.
+ * Rows of several layers are processed in one launch: v and W are flat buffers, row r of
+ * length row_len[r] starts at row_off[r] (device int32 arrays, n_rows entries). */
+int mmb_weight_norm(int n_rows, const int32_t* row_off, const int32_t* row_len,
+                    const float* v, const float* g, float* W, float* inv_norm, void* stream);
+int mmb_weight_norm_bwd(int n_rows, const int32_t* row_off, const int32_t* row_len,
+                        const float* v, const float* g, const float* inv_norm, const float* dW,
+                        float* dv, float* dg, void* stream);
+
+/* Y = act( cat_s[X_s] @ W^T + bias ) (+ residual): the weight-normed Linear of epic.py
+ * (F.linear on a torch.cat of [time | x_local | broadcast global], epic.py:95,155,203) with
+ * the concatenation never materialised.  M rows, rows_per_jet = N (jet of row r is r/N).
+ * Segments (HOST arrays of length n_seg <= 4): seg_ptr (device pointers), seg_width,
+ * seg_kind (MMB_SEG_*), seg_ld (leading dimension in elements).  W is (Nout, K) row-major
+ * with leading dimension w_ld (a column slice of a wider matrix is allowed).
+ * pre_act (M,Nout) | NULL stores the pre-activation (needed by the GELU backward).
+ * row_scale (M) | NULL multiplies the finished row. */
+int mmb_linear_cat(int M, int rows_per_jet, int n_seg,
+                   const void* const* seg_ptr_host, const int* seg_width_host,
+                   const int* seg_kind_host, const int* seg_ld_host,
+                   const float* maskf,
+                   const float* W, int64_t w_ld, const float* bias,
+                   int Nout, int act, const float* residual, int64_t res_ld,
+                   const float* row_scale,
+                   float* Y, int64_t y_ld, float* pre_act, void* stream);
+
+/* EPiCEncoder._meansum_pool (epic.py:100-107) without the concat:
+ * pooled[b, 0:H] = sum_n x*mask / counts[b] ; pooled[b, H:2H] = 0.01 * sum_n x*mask. */
+int mmb_meansum_pool(int B, int N, int H, const float* x, int64_t x_ld, const float* maskf,
+                     const int32_t* counts, float* pooled, int64_t pooled_ld, void* stream);
+
+/* MultiModalEmbedder (embedder.py:63-97) + apply_mask (tensorclass.py:96-106):
+ *   temb (B,Et)        = Linear(cat[sin(2 pi t W), cos(2 pi t W)])      per jet
+ *   cont (B,N,Ec) f32  = (x @ Wc^T + bc) * mask                          (NULL to skip)
+ *   disc (B,N,Ed) f32  = trunc( table[k] * mask )  -- quirk Q1: the reference truncates the
+ *                        embedded features to int64; we store the truncated value as f32
+ *                        (every consumer promotes it back to f32, epic.py:155)
+ * table (V,Ed) is the weight-normed embedding  g*v/||v||. */
+int mmb_embed(int B, int N, int Dc, int V, int Et, int Ec, int Ed,
+              const float* t, float t_scalar, const float* x, const int64_t* k, const float* maskf,
+              const float* fourier_W, const float* time_W, const float* time_b,
+              const float* cont_W, const float* cont_b, const float* table,
+              float* temb, float* cont, float* disc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMB_HIP_H */

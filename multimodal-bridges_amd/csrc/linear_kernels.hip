@@ -1,0 +1,445 @@
+// K-E (generic, layer-at-a-time): fp32 MFMA linear layer over a never-materialised
+// concatenation, weight-norm, masked mean/sum pooling and the embedder.
+// Reference: encoders/epic.py:71-107,145-159,187-208; encoders/embedder.py:63-97.
+//
+// mmb_linear_cat tiling (gfx950, wave64): a block of WAVES waves owns WAVES*32 rows x BN
+// columns; each wave owns 32 rows and BN/32 accumulator tiles of v_mfma_f32_32x32x2_f32
+// (exact fp32, 64 FLOP/clk/SIMD).  Activation rows are read ONCE by exactly one wave, so
+// they go straight from global memory to the A fragments (no LDS round trip); the weight
+// chunk [BN x BK] is shared by all waves of the block and is double-buffered through LDS.
+// Inside a K chunk the MFMA k index is permuted (k = half*BK/2 + step) so that every lane
+// reads BK/2 CONTIGUOUS floats for its fragment (dwordx4 global loads, ds_read_b128).
+#include "common.h"
+
+namespace mmb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Seg {
+  const float* ptr;
+  int width;
+  int kind;
+  int ld;
+  int k_begin;
+};
+struct Segs {
+  Seg s[4];
+  int n;
+};
+
+__device__ inline float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ inline float apply_act(int act, float x) {
+  if (act == MMB_ACT_GELU) return gelu_exact(x);
+  if (act == MMB_ACT_LRELU) return x > 0.0f ? x : 0.01f * x;
+  return x;
+}
+
+// generic element fetch of the concatenated input (slow path only)
+__device__ inline float fetch_cat(const Segs& sg, int row, int jet, float m, int k) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < sg.n) {
+      const Seg& s = sg.s[i];
+      if (k >= s.k_begin && k < s.k_begin + s.width) {
+        int kk = k - s.k_begin;
+        if (s.kind == MMB_SEG_ROW) return s.ptr[(int64_t)row * s.ld + kk];
+        float v = s.ptr[(int64_t)jet * s.ld + kk];
+        return s.kind == MMB_SEG_JET_MASK ? v * m : v;
+      }
+    }
+  }
+  return 0.0f;
+}
+
+template <int WAVES, int NT, int BK, bool ALIGNED>
+__global__ void __launch_bounds__(WAVES * 64)
+linear_cat_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restrict__ maskf,
+                  const float* __restrict__ W, int64_t w_ld, const float* __restrict__ bias, int Nout,
+                  int act, const float* __restrict__ residual, int64_t res_ld,
+                  const float* __restrict__ row_scale, float* __restrict__ Y, int64_t y_ld,
+                  float* __restrict__ pre_act) {
+  constexpr int BN = NT * 32;
+  constexpr int HALF = BK / 2;
+  constexpr int PITCH = BK + 4;                 // conflict-free for ds_read_b128
+  constexpr int THREADS = WAVES * 64;
+  constexpr int W_F4 = BN * BK / 4;             // float4 per W chunk
+  constexpr int W_PER_T = (W_F4 + THREADS - 1) / THREADS;
+  __shared__ __attribute__((aligned(16))) float Ws[2][BN * PITCH];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int half = lane >> 5;
+  const int r32 = lane & 31;
+  const int row0 = blockIdx.x * (WAVES * 32) + wave * 32;
+  const int col0 = blockIdx.y * BN;
+  const int my_row = row0 + r32;
+  const int ld_row = my_row < M ? my_row : M - 1;     // clamp loads; stores are guarded
+  const int jet = ld_row / rows_per_jet;
+  const float m = maskf ? maskf[ld_row] : 1.0f;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+
+  const int nchunks = (K + BK - 1) / BK;
+  float a_next[HALF];
+  float4 w_next[W_PER_T];
+
+  auto load_a = [&](int chunk) {
+    const int kh = chunk * BK + half * HALF;
+    if constexpr (ALIGNED) {
+      // segments are HALF-aligned: this lane's HALF values live in one segment
+      const float* src = nullptr;
+      float scale = 1.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < sg.n && kh >= sg.s[i].k_begin && kh < sg.s[i].k_begin + sg.s[i].width) {
+          const Seg& s = sg.s[i];
+          const int64_t base = (s.kind == MMB_SEG_ROW) ? (int64_t)ld_row * s.ld : (int64_t)jet * s.ld;
+          src = s.ptr + base + (kh - s.k_begin);
+          scale = (s.kind == MMB_SEG_JET_MASK) ? m : 1.0f;
+        }
+      }
+      if (src != nullptr) {
+#pragma unroll
+        for (int q = 0; q < HALF / 4; ++q) {
+          float4 v = reinterpret_cast<const float4*>(src)[q];
+          a_next[4 * q + 0] = v.x * scale; a_next[4 * q + 1] = v.y * scale;
+          a_next[4 * q + 2] = v.z * scale; a_next[4 * q + 3] = v.w * scale;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < HALF; ++q) a_next[q] = 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < HALF; ++q) a_next[q] = fetch_cat(sg, ld_row, jet, m, kh + q);
+    }
+  };
+
+  auto load_w = [&](int chunk) {
+    const int k0 = chunk * BK;
+#pragma unroll
+    for (int q = 0; q < W_PER_T; ++q) {
+      const int idx = tid + q * THREADS;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < W_F4) {
+        const int o = idx / (BK / 4);
+        const int c4 = idx % (BK / 4);
+        const int go = col0 + o;
+        const int gk = k0 + 4 * c4;
+        if (go < Nout) {
+          const float* wp = W + (int64_t)go * w_ld + gk;
+          if constexpr (ALIGNED) {
+            if (gk < K) v = *reinterpret_cast<const float4*>(wp);
+          } else {
+            v.x = gk + 0 < K ? wp[0] : 0.f; v.y = gk + 1 < K ? wp[1] : 0.f;
+            v.z = gk + 2 < K ? wp[2] : 0.f; v.w = gk + 3 < K ? wp[3] : 0.f;
+          }
+        }
+      }
+      w_next[q] = v;
+    }
+  };
+
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < W_PER_T; ++q) {
+      const int idx = tid + q * THREADS;
+      if (idx < W_F4) {
+        const int o = idx / (BK / 4);
+        const int c4 = idx % (BK / 4);
+        *reinterpret_cast<float4*>(&Ws[buf][o * PITCH + 4 * c4]) = w_next[q];
+      }
+    }
+  };
+
+  load_a(0);
+  load_w(0);
+  store_w(0);
+
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();                              // Ws[c&1] complete; Ws[(c+1)&1] free
+    float a_cur[HALF];
+#pragma unroll
+    for (int q = 0; q < HALF; ++q) a_cur[q] = a_next[q];
+    if (c + 1 < nchunks) {
+      load_a(c + 1);
+      load_w(c + 1);
+    }
+    const float* wbuf = Ws[c & 1];
+#pragma unroll
+    for (int s4 = 0; s4 < HALF / 4; ++s4) {
+      float4 b[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        b[j] = *reinterpret_cast<const float4*>(&wbuf[(j * 32 + r32) * PITCH + half * HALF + 4 * s4]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[4 * s4 + 0], b[j].x, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[4 * s4 + 1], b[j].y, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[4 * s4 + 2], b[j].z, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[4 * s4 + 3], b[j].w, acc[j], 0, 0, 0);
+    }
+    if (c + 1 < nchunks) store_w((c + 1) & 1);
+  }
+
+  // epilogue.  C/D layout of 32x32x2: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = col0 + j * 32 + r32;
+    if (col >= Nout) continue;
+    const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+      if (row >= M) continue;
+      float z = acc[j][i] + bv;
+      if (pre_act) pre_act[(int64_t)row * Nout + col] = z;
+      float y = apply_act(act, z);
+      if (residual) y += residual[(int64_t)row * res_ld + col];
+      if (row_scale) y *= row_scale[row];
+      Y[(int64_t)row * y_ld + col] = y;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- weight norm ----------
+__global__ void __launch_bounds__(64)
+weight_norm_kernel(int n_rows, const int32_t* __restrict__ row_off, const int32_t* __restrict__ row_len,
+                   const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ W,
+                   float* __restrict__ inv_norm) {
+  const int r = blockIdx.x;
+  const int off = row_off[r], len = row_len[r];
+  float ss = 0.0f;
+  for (int k = threadIdx.x; k < len; k += 64) { float a = v[off + k]; ss += a * a; }
+  ss = wave_sum(ss);
+  const float nrm = sqrtf(ss);
+  const float scale = g[r] / nrm;
+  for (int k = threadIdx.x; k < len; k += 64) W[off + k] = v[off + k] * scale;
+  if (inv_norm && threadIdx.x == 0) inv_norm[r] = 1.0f / nrm;
+}
+
+__global__ void __launch_bounds__(64)
+weight_norm_bwd_kernel(int n_rows, const int32_t* __restrict__ row_off, const int32_t* __restrict__ row_len,
+                       const float* __restrict__ v, const float* __restrict__ g,
+                       const float* __restrict__ inv_norm, const float* __restrict__ dW,
+                       float* __restrict__ dv, float* __restrict__ dg) {
+  const int r = blockIdx.x;
+  const int off = row_off[r], len = row_len[r];
+  float dot = 0.0f;
+  for (int k = threadIdx.x; k < len; k += 64) dot += dW[off + k] * v[off + k];
+  dot = wave_sum(dot);
+  const float inv = inv_norm[r];
+  const float gg = g[r];
+  const float c1 = gg * inv;
+  const float c2 = gg * dot * inv * inv * inv;
+  for (int k = threadIdx.x; k < len; k += 64) dv[off + k] = c1 * dW[off + k] - c2 * v[off + k];
+  if (threadIdx.x == 0) dg[r] = dot * inv;
+}
+
+// ---------------------------------------------------------------- pooling --------------
+__global__ void __launch_bounds__(256)
+meansum_pool_kernel(int N, int H, const float* __restrict__ x, int64_t x_ld, const float* __restrict__ maskf,
+                    const int32_t* __restrict__ counts, float* __restrict__ pooled, int64_t pooled_ld) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.x;
+  const int col = threadIdx.x & 63;
+  const int rg = threadIdx.x >> 6;
+  const float cnt = (float)counts[b];
+  for (int c0 = 0; c0 < H; c0 += 64) {
+    const int c = c0 + col;
+    float s = 0.0f;
+    if (c < H)
+      for (int n = rg; n < N; n += 4) {
+        const int64_t p = (int64_t)b * N + n;
+        s += x[p * x_ld + c] * maskf[p];
+      }
+    red[rg][col] = s;
+    __syncthreads();
+    if (rg == 0 && c < H) {
+      const float tot = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+      pooled[(int64_t)b * pooled_ld + c] = tot / cnt;
+      pooled[(int64_t)b * pooled_ld + H + c] = tot * 0.01f;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- embedder -------------
+__global__ void __launch_bounds__(64)
+time_embed_kernel(int Et, const float* __restrict__ t, float t_scalar, const float* __restrict__ fW,
+                  const float* __restrict__ lw, const float* __restrict__ lb, float* __restrict__ temb) {
+  extern __shared__ float feat[];                  // Et fourier features
+  const int b = blockIdx.x;
+  const float tt = t ? t[b] : t_scalar;
+  const int hE = Et / 2;
+  for (int i = threadIdx.x; i < hE; i += 64) {
+    float a = tt * fW[i];
+    a = a * 2.0f;
+    a = a * 3.14159265358979323846f;
+    feat[i] = sinf(a);
+    feat[hE + i] = cosf(a);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < Et; o += 64) {
+    float s = 0.0f;
+    for (int k = 0; k < 2 * hE; ++k) s += feat[k] * lw[o * Et + k];
+    temb[(int64_t)b * Et + o] = s + lb[o];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+particle_embed_kernel(int P, int Dc, int Ec, int Ed, const float* __restrict__ x, const int64_t* __restrict__ k,
+                      const float* __restrict__ maskf, const float* __restrict__ cW,
+                      const float* __restrict__ cb, const float* __restrict__ table,
+                      float* __restrict__ cont, float* __restrict__ disc) {
+  // one lane per (particle, output feature); consecutive lanes -> consecutive features
+  const int F = Ec + Ed;
+  const int64_t total = (int64_t)P * F;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i / F);
+    const int f = (int)(i - (int64_t)p * F);
+    const float m = maskf[p];
+    if (f < Ec) {
+      float s = 0.0f;
+      for (int d = 0; d < Dc; ++d) s += x[(int64_t)p * Dc + d] * cW[f * Dc + d];
+      cont[(int64_t)p * Ec + f] = (s + cb[f]) * m;
+    } else {
+      const int e = f - Ec;
+      disc[(int64_t)p * Ed + e] = truncf(table[(int)k[p] * Ed + e] * m);      // quirk Q1
+    }
+  }
+}
+
+template <int WAVES, int NT, int BK, bool ALIGNED>
+static void launch_linear(dim3 grid, hipStream_t st, int M, int rpj, const Segs& sg, int K, const float* maskf,
+                          const float* W, int64_t w_ld, const float* bias, int Nout, int act, const float* residual,
+                          int64_t res_ld, const float* row_scale, float* Y, int64_t y_ld, float* pre_act) {
+  hipLaunchKernelGGL((linear_cat_kernel<WAVES, NT, BK, ALIGNED>), grid, dim3(WAVES * 64), 0, st, M, rpj, sg, K,
+                     maskf, W, w_ld, bias, Nout, act, residual, res_ld, row_scale, Y, y_ld, pre_act);
+}
+
+}  // namespace mmb
+
+using namespace mmb;
+
+extern "C" int mmb_linear_cat(int M, int rows_per_jet, int n_seg, const void* const* seg_ptr, const int* seg_width,
+                              const int* seg_kind, const int* seg_ld, const float* maskf, const float* W,
+                              int64_t w_ld, const float* bias, int Nout, int act, const float* residual,
+                              int64_t res_ld, const float* row_scale, float* Y, int64_t y_ld, float* pre_act,
+                              void* stream) {
+  MMB_REQUIRE(M > 0 && Nout > 0, "mmb_linear_cat: empty shape M=%d Nout=%d", M, Nout);
+  MMB_REQUIRE(rows_per_jet > 0, "mmb_linear_cat: rows_per_jet must be > 0");
+  MMB_REQUIRE(n_seg >= 1 && n_seg <= 4, "mmb_linear_cat: n_seg=%d outside [1,4]", n_seg);
+  MMB_REQUIRE(seg_ptr && seg_width && seg_kind && seg_ld && W && Y, "mmb_linear_cat: NULL argument");
+  MMB_REQUIRE(act >= 0 && act <= 2, "mmb_linear_cat: bad activation %d", act);
+  Segs sg;
+  sg.n = n_seg;
+  int K = 0;
+  bool al16 = true, al8 = true;
+  for (int i = 0; i < 4; ++i) {
+    if (i < n_seg) {
+      MMB_REQUIRE(seg_ptr[i] && seg_width[i] > 0, "mmb_linear_cat: segment %d empty", i);
+      MMB_REQUIRE(seg_kind[i] >= 0 && seg_kind[i] <= 2, "mmb_linear_cat: segment %d bad kind %d", i, seg_kind[i]);
+      MMB_REQUIRE(seg_ld[i] >= seg_width[i], "mmb_linear_cat: segment %d ld < width", i);
+      if (seg_kind[i] == MMB_SEG_JET_MASK) MMB_REQUIRE(maskf, "mmb_linear_cat: JET_MASK segment needs maskf");
+      sg.s[i] = Seg{(const float*)seg_ptr[i], seg_width[i], seg_kind[i], seg_ld[i], K};
+      K += seg_width[i];
+      bool a4 = (seg_ld[i] % 4 == 0) && ((reinterpret_cast<uintptr_t>(seg_ptr[i]) & 15) == 0);
+      al16 = al16 && a4 && (seg_width[i] % 16 == 0);
+      al8 = al8 && a4 && (seg_width[i] % 8 == 0);
+    } else {
+      sg.s[i] = Seg{nullptr, 0, 0, 0, 0};
+    }
+  }
+  MMB_REQUIRE(w_ld >= K, "mmb_linear_cat: w_ld=%lld < K=%d", (long long)w_ld, K);
+  bool w_al = (w_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+  al16 = al16 && w_al;
+  al8 = al8 && w_al;
+  hipStream_t st = as_stream(stream);
+  const bool small_m = M <= 4096;                // per-jet rows: one wave per block for parallelism
+  const int nt = Nout <= 32 ? 1 : (Nout <= 64 ? 2 : 4);
+  const int bm = small_m ? 32 : 128;
+  dim3 grid((M + bm - 1) / bm, (Nout + nt * 32 - 1) / (nt * 32));
+#define MMB_LAUNCH(WV, NT_, BK_, AL)                                                                           \
+  launch_linear<WV, NT_, BK_, AL>(grid, st, M, rows_per_jet, sg, K, maskf, W, w_ld, bias, Nout, act, residual, \
+                                  res_ld, row_scale, Y, y_ld, pre_act)
+#define MMB_PICK_NT(WV, BK_, AL)                \
+  do {                                          \
+    if (nt == 1) MMB_LAUNCH(WV, 1, BK_, AL);    \
+    else if (nt == 2) MMB_LAUNCH(WV, 2, BK_, AL); \
+    else MMB_LAUNCH(WV, 4, BK_, AL);            \
+  } while (0)
+  if (small_m) {
+    if (al16) MMB_PICK_NT(1, 32, true);
+    else if (al8) MMB_PICK_NT(1, 16, true);
+    else MMB_PICK_NT(1, 16, false);
+  } else {
+    if (al16) MMB_PICK_NT(4, 32, true);
+    else if (al8) MMB_PICK_NT(4, 16, true);
+    else MMB_PICK_NT(4, 16, false);
+  }
+#undef MMB_PICK_NT
+#undef MMB_LAUNCH
+  return check_launch("mmb_linear_cat");
+}
+
+extern "C" int mmb_weight_norm(int n_rows, const int32_t* row_off, const int32_t* row_len, const float* v,
+                               const float* g, float* W, float* inv_norm, void* stream) {
+  MMB_REQUIRE(n_rows > 0, "mmb_weight_norm: n_rows=%d", n_rows);
+  MMB_REQUIRE(row_off && row_len && v && g && W, "mmb_weight_norm: NULL argument");
+  hipLaunchKernelGGL(weight_norm_kernel, dim3(n_rows), dim3(64), 0, as_stream(stream), n_rows, row_off, row_len, v,
+                     g, W, inv_norm);
+  return check_launch("mmb_weight_norm");
+}
+
+extern "C" int mmb_weight_norm_bwd(int n_rows, const int32_t* row_off, const int32_t* row_len, const float* v,
+                                   const float* g, const float* inv_norm, const float* dW, float* dv, float* dg,
+                                   void* stream) {
+  MMB_REQUIRE(n_rows > 0, "mmb_weight_norm_bwd: n_rows=%d", n_rows);
+  MMB_REQUIRE(row_off && row_len && v && g && inv_norm && dW && dv && dg, "mmb_weight_norm_bwd: NULL argument");
+  hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(n_rows), dim3(64), 0, as_stream(stream), n_rows, row_off,
+                     row_len, v, g, inv_norm, dW, dv, dg);
+  return check_launch("mmb_weight_norm_bwd");
+}
+
+extern "C" int mmb_meansum_pool(int B, int N, int H, const float* x, int64_t x_ld, const float* maskf,
+                                const int32_t* counts, float* pooled, int64_t pooled_ld, void* stream) {
+  MMB_REQUIRE(B > 0 && N > 0 && H > 0, "mmb_meansum_pool: empty shape");
+  MMB_REQUIRE(x && maskf && counts && pooled, "mmb_meansum_pool: NULL argument");
+  MMB_REQUIRE(x_ld >= H && pooled_ld >= 2 * H, "mmb_meansum_pool: leading dimensions too small");
+  hipLaunchKernelGGL(meansum_pool_kernel, dim3(B), dim3(256), 0, as_stream(stream), N, H, x, x_ld, maskf, counts,
+                     pooled, pooled_ld);
+  return check_launch("mmb_meansum_pool");
+}
+
+extern "C" int mmb_embed(int B, int N, int Dc, int V, int Et, int Ec, int Ed, const float* t, float t_scalar,
+                         const float* x, const int64_t* k, const float* maskf, const float* fourier_W,
+                         const float* time_W, const float* time_b, const float* cont_W, const float* cont_b,
+                         const float* table, float* temb, float* cont, float* disc, void* stream) {
+  MMB_REQUIRE(B > 0 && N > 0, "mmb_embed: empty shape");
+  MMB_REQUIRE(Et > 0 && Et % 2 == 0, "mmb_embed: dim_emb_time=%d must be even and > 0", Et);
+  MMB_REQUIRE(fourier_W && time_W && time_b && temb && maskf, "mmb_embed: NULL argument");
+  const bool has_c = cont != nullptr, has_d = disc != nullptr;
+  if (has_c) MMB_REQUIRE(x && cont_W && cont_b && Dc > 0 && Ec > 0, "mmb_embed: continuous mode needs x,cont_W,cont_b");
+  if (has_d) MMB_REQUIRE(k && table && Ed > 0 && V > 0, "mmb_embed: discrete mode needs k,table");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(time_embed_kernel, dim3(B), dim3(64), Et * sizeof(float), st, Et, t, t_scalar, fourier_W,
+                     time_W, time_b, temb);
+  int rc = check_launch("mmb_embed(time)");
+  if (rc) return rc;
+  if (has_c || has_d) {
+    const int P = B * N;
+    const int ec = has_c ? Ec : 0, ed = has_d ? Ed : 0;
+    hipLaunchKernelGGL(particle_embed_kernel, dim3(stream_grid((int64_t)P * (ec + ed), 256)), dim3(256), 0, st, P,
+                       Dc, ec, ed, x, k, maskf, cont_W, cont_b, table, cont, disc);
+    rc = check_launch("mmb_embed(particles)");
+  }
+  return rc;
+}

@@ -1,0 +1,180 @@
+// K-F: masked MSE + masked cross-entropy, forward and head gradients in one pass; mask
+// canonicalisation; MultiModeLoss.  Reference: model/multimodal_bridge_matching.py:165-192,268-306.
+#include "common.h"
+
+namespace mmb {
+
+__device__ inline float drift_value2(int bridge_kind, float t, float xt, float x0, float x1) {
+  if (bridge_kind == MMB_BRIDGE_SCHRODINGER) {
+    float den = t * (1.0f - t);
+    float A = (1.0f - 2.0f * t) / den;
+    float Bc = (t * t) / den;
+    float C = -1.0f * ((1.0f - t) * (1.0f - t)) / den;
+    return A * xt + Bc * x1 + C * x0;
+  }
+  return 0.0f * xt + 1.0f * x1 + (-1.0f) * x0;
+}
+
+constexpr int LOSS_MAXV = 32;
+
+__global__ void __launch_bounds__(256)
+loss_kernel(int P, int N, int Dc, int V, const float* __restrict__ head_c, const float* __restrict__ head_d,
+            const float* __restrict__ t, const float* __restrict__ xt, const float* __restrict__ x0,
+            const float* __restrict__ x1, int bridge_kind, const int64_t* __restrict__ k1,
+            const float* __restrict__ maskf, const int32_t* __restrict__ total,
+            const float* __restrict__ vocab_freq, const float* __restrict__ coef,
+            float* __restrict__ partials, float* __restrict__ d_head_c, float* __restrict__ d_head_d) {
+  __shared__ float red[2][4];
+  const float msum = (float)total[0];
+  const float gc = coef ? coef[0] / msum : 0.0f;
+  const float gd = coef ? coef[1] / msum : 0.0f;
+  float acc_c = 0.0f, acc_d = 0.0f;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+    const float m = maskf[p];
+    if (head_c != nullptr) {
+      const float tt = t[p / N];
+      const int64_t base = (int64_t)p * Dc;
+      for (int d = 0; d < Dc; ++d) {
+        float target = drift_value2(bridge_kind, tt, xt[base + d], x0[base + d], x1[base + d]);
+        float diff = head_c[base + d] - target;
+        acc_c += (diff * diff) * m;
+        if (d_head_c) d_head_c[base + d] = gc * 2.0f * diff * m;
+      }
+    }
+    if (head_d != nullptr) {
+      const float* lp = head_d + (int64_t)p * V;
+      const int y = (int)k1[p];
+      float mx = -INFINITY;
+      for (int v = 0; v < V; ++v) mx = fmaxf(mx, lp[v]);
+      float s = 0.0f;
+      for (int v = 0; v < V; ++v) s += expf(lp[v] - mx);
+      const float lse = mx + logf(s);
+      const float wy = vocab_freq ? vocab_freq[y] : 1.0f;
+      acc_d += (wy * (lse - lp[y])) * m;
+      if (d_head_d) {
+        float* gp = d_head_d + (int64_t)p * V;
+        const float sc = gd * wy * m;
+        for (int v = 0; v < V; ++v) gp[v] = sc * (expf(lp[v] - lse) - (v == y ? 1.0f : 0.0f));
+      }
+    }
+  }
+  acc_c = wave_sum(acc_c);
+  acc_d = wave_sum(acc_d);
+  const int wid = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wid] = acc_c; red[1][wid] = acc_d; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    partials[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+__global__ void loss_finalize_kernel(int nblocks, const float* __restrict__ partials,
+                                     const int32_t* __restrict__ total, float* __restrict__ losses) {
+  // one wave; deterministic order
+  float a = 0.0f, b = 0.0f;
+  for (int i = threadIdx.x; i < nblocks; i += 64) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if (threadIdx.x == 0) {
+    const float msum = (float)total[0];
+    losses[0] = a / msum;
+    losses[1] = b / msum;
+  }
+}
+
+__global__ void multimode_kernel(const float* losses, const float* s, float w0, float w1, float* coef_out,
+                                 float* loss_out, float* d_s) {
+  if (threadIdx.x != 0) return;
+  float c0, c1;
+  if (s != nullptr) { c0 = 0.5f * expf(-s[0]); c1 = 0.5f * expf(-s[1]); } else { c0 = w0; c1 = w1; }
+  if (coef_out) { coef_out[0] = c0; coef_out[1] = c1; }
+  if (loss_out) {
+    float l = c0 * losses[0] + c1 * losses[1];
+    if (s != nullptr) l = (c0 * losses[0] + 0.5f * s[0]) + (c1 * losses[1] + 0.5f * s[1]);
+    loss_out[0] = l;
+  }
+  if (d_s && s) { d_s[0] = -c0 * losses[0] + 0.5f; d_s[1] = -c1 * losses[1] + 0.5f; }
+}
+
+template <typename MT>
+__global__ void __launch_bounds__(64)
+mask_prepare_kernel(int N, const MT* __restrict__ mask, float* __restrict__ maskf, int32_t* __restrict__ counts,
+                    int32_t* __restrict__ total) {
+  const int b = blockIdx.x;
+  int cnt = 0;
+  for (int n = threadIdx.x; n < N; n += 64) {
+    bool on = mask[(int64_t)b * N + n] != (MT)0;
+    maskf[(int64_t)b * N + n] = on ? 1.0f : 0.0f;
+    cnt += on ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if (threadIdx.x == 0) {
+    counts[b] = cnt;
+    if (total) atomicAdd(total, cnt);
+  }
+}
+
+}  // namespace mmb
+
+using namespace mmb;
+
+extern "C" int mmb_mask_prepare(int B, int N, const void* mask, int mask_is_i64, float* maskf, int32_t* counts,
+                                int32_t* total, void* stream) {
+  MMB_REQUIRE(B > 0 && N > 0, "mmb_mask_prepare: empty shape B=%d N=%d", B, N);
+  MMB_REQUIRE(mask && maskf && counts, "mmb_mask_prepare: NULL argument");
+  if (total) {
+    hipError_t e = hipMemsetAsync(total, 0, sizeof(int32_t), as_stream(stream));
+    if (e != hipSuccess) { set_error("mmb_mask_prepare: memset failed: %s", hipGetErrorString(e)); return MMB_ERR_LAUNCH; }
+  }
+  if (mask_is_i64)
+    hipLaunchKernelGGL(mask_prepare_kernel<int64_t>, dim3(B), dim3(64), 0, as_stream(stream), N,
+                       (const int64_t*)mask, maskf, counts, total);
+  else
+    hipLaunchKernelGGL(mask_prepare_kernel<float>, dim3(B), dim3(64), 0, as_stream(stream), N, (const float*)mask,
+                       maskf, counts, total);
+  return check_launch("mmb_mask_prepare");
+}
+
+extern "C" int mmb_loss_fwd_bwd(int B, int N, int Dc, int V, const float* head_c, const float* head_d,
+                                const float* t, const float* xt, const float* x0, const float* x1, int bridge_kind,
+                                const int64_t* k1, const float* maskf, const int32_t* total,
+                                const float* vocab_freq, const float* coef, float* partials, float* losses,
+                                float* d_head_c, float* d_head_d, void* stream) {
+  MMB_REQUIRE(B > 0 && N > 0, "mmb_loss_fwd_bwd: empty shape");
+  MMB_REQUIRE((int64_t)B * N < (1ll << 31), "mmb_loss_fwd_bwd: B*N too large");
+  MMB_REQUIRE(head_c || head_d, "mmb_loss_fwd_bwd: no head given");
+  MMB_REQUIRE(maskf && total && partials && losses, "mmb_loss_fwd_bwd: NULL argument");
+  if (head_c) MMB_REQUIRE(t && xt && x0 && x1 && Dc > 0, "mmb_loss_fwd_bwd: continuous head needs t,xt,x0,x1");
+  if (head_d) MMB_REQUIRE(k1 && V > 1 && V <= LOSS_MAXV, "mmb_loss_fwd_bwd: discrete head needs k1, 1<V<=32");
+  if (d_head_c || d_head_d) MMB_REQUIRE(coef, "mmb_loss_fwd_bwd: gradients need coef");
+  int P = B * N;
+  int grid = (P + 255) / 256;
+  if (grid > MMB_LOSS_MAX_BLOCKS) grid = MMB_LOSS_MAX_BLOCKS;
+  hipLaunchKernelGGL(loss_kernel, dim3(grid), dim3(256), 0, as_stream(stream), P, N, Dc, V, head_c, head_d, t, xt,
+                     x0, x1, bridge_kind, k1, maskf, total, vocab_freq, coef, partials, d_head_c, d_head_d);
+  int rc = check_launch("mmb_loss_fwd_bwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), grid, partials, total, losses);
+  return check_launch("mmb_loss_fwd_bwd(finalize)");
+}
+
+extern "C" int mmb_multimode_coef(const float* s, const float* fixed_w_host2, float* coef_out, void* stream) {
+  MMB_REQUIRE(coef_out, "mmb_multimode_coef: NULL output");
+  MMB_REQUIRE(s || fixed_w_host2, "mmb_multimode_coef: need learnable s or fixed weights");
+  float w0 = fixed_w_host2 ? fixed_w_host2[0] : 0.0f, w1 = fixed_w_host2 ? fixed_w_host2[1] : 0.0f;
+  hipLaunchKernelGGL(multimode_kernel, dim3(1), dim3(64), 0, as_stream(stream), (const float*)nullptr, s, w0, w1,
+                     coef_out, (float*)nullptr, (float*)nullptr);
+  return check_launch("mmb_multimode_coef");
+}
+
+extern "C" int mmb_multimode_loss(const float* losses, const float* s, const float* fixed_w_host2, float* loss_out,
+                                  float* d_s, void* stream) {
+  MMB_REQUIRE(losses && loss_out, "mmb_multimode_loss: NULL argument");
+  MMB_REQUIRE(s || fixed_w_host2, "mmb_multimode_loss: need learnable s or fixed weights");
+  float w0 = fixed_w_host2 ? fixed_w_host2[0] : 0.0f, w1 = fixed_w_host2 ? fixed_w_host2[1] : 0.0f;
+  hipLaunchKernelGGL(multimode_kernel, dim3(1), dim3(64), 0, as_stream(stream), losses, s, w0, w1,
+                     (float*)nullptr, loss_out, d_s);
+  return check_launch("mmb_multimode_loss");
+}

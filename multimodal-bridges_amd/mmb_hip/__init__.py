@@ -1,0 +1,86 @@
+"""ctypes binding of libmmb_hip.so (the C ABI declared in include/mmb_hip.h).
+
+The library is built in-tree by mmb_hip.build (hipcc, gfx950).  There is NO fallback: if the
+shared object is missing, or an op is handed a tensor that does not live on a HIP device,
+the call raises -- the product path never runs on the CPU.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmb_hip.so")
+
+c_f32p = C.c_void_p     # device pointers travel as plain addresses
+c_i64p = C.c_void_p
+c_i32p = C.c_void_p
+c_stream = C.c_void_p
+
+# name -> argtypes; MUST list every symbol include/mmb_hip.h declares (tests check this)
+SIGNATURES = {
+    "mmb_version": [],
+    "mmb_mask_prepare": [C.c_int, C.c_int, C.c_void_p, C.c_int, c_f32p, c_i32p, c_i32p, c_stream],
+    "mmb_source_uniform": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, C.c_uint64, C.c_uint64,
+                           c_f32p, c_i64p, c_i64p, c_f32p, c_i32p, c_stream],
+    "mmb_bridge_sample": [C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_float, c_f32p, c_f32p, c_f32p,
+                          c_i64p, c_i64p, c_f32p, C.c_int, C.c_float, C.c_int, C.c_float,
+                          c_f32p, c_f32p, c_i64p, c_stream],
+    "mmb_bridge_sample_rng": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, c_i64p, C.c_int, C.c_float,
+                              C.c_int, C.c_float, C.c_uint64, C.c_uint64, c_f32p, c_f32p, c_i64p, c_f32p,
+                              c_i64p, c_stream],
+    "mmb_telegraph_probs": [C.c_int, C.c_int, C.c_int, c_f32p, c_i64p, c_i64p, C.c_int, C.c_float, c_f32p, c_stream],
+    "mmb_bridge_drift": [C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, c_stream],
+    "mmb_euler_step": [C.c_int64, c_f32p, c_f32p, C.c_float, c_stream],
+    "mmb_euler_maruyama_step": [C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_float, c_f32p, C.c_float,
+                                C.c_float, c_f32p, C.c_uint64, C.c_uint64, c_stream],
+    "mmb_telegraph_rate": [C.c_int, C.c_int, C.c_int, c_f32p, c_i64p, c_f32p, C.c_float, C.c_int, C.c_float,
+                           c_f32p, c_stream],
+    "mmb_rate_tauleap": [C.c_int, C.c_int, C.c_int, c_f32p, c_i64p, c_f32p, C.c_float, C.c_float, C.c_int,
+                         C.c_float, c_f32p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, c_f32p, c_stream],
+    "mmb_rate_euler_jump": [C.c_int, C.c_int, C.c_int, c_f32p, c_i64p, c_f32p, C.c_float, C.c_float, C.c_int,
+                            C.c_float, c_f32p, C.c_uint64, C.c_uint64, C.c_int, c_f32p, c_stream],
+    "mmb_loss_fwd_bwd": [C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                         C.c_int, c_i64p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
+    "mmb_multimode_coef": [c_f32p, C.POINTER(C.c_float), c_f32p, c_stream],
+    "mmb_multimode_loss": [c_f32p, c_f32p, C.POINTER(C.c_float), c_f32p, c_f32p, c_stream],
+    "mmb_weight_norm": [C.c_int, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
+    "mmb_weight_norm_bwd": [C.c_int, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
+    "mmb_linear_cat": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                       C.POINTER(C.c_int), c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int, C.c_int, c_f32p, C.c_int64,
+                       c_f32p, c_f32p, C.c_int64, c_f32p, c_stream],
+    "mmb_meansum_pool": [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, c_i32p, c_f32p, C.c_int64, c_stream],
+    "mmb_embed": [C.c_int] * 7 + [c_f32p, C.c_float, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                  c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
+}
+
+_lib = None
+
+
+class MMBError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MMBError(
+                f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        h = C.CDLL(LIB_PATH)
+        h.mmb_last_error.restype = C.c_char_p
+        h.mmb_last_error.argtypes = []
+        for name, args in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        _lib = h
+    return _lib
+
+
+def call(name, *args):
+    h = lib()
+    rc = getattr(h, name)(*args)
+    if rc != 0:
+        raise MMBError(f"{name} failed (rc={rc}): {h.mmb_last_error().decode()}")
+    return rc

@@ -1,0 +1,294 @@
+"""Tensor-level wrappers over the C ABI: validate device/dtype/contiguity, allocate outputs
+with torch (plumbing only), enqueue on torch's current HIP stream.  No host syncs."""
+import ctypes as C
+
+import torch
+
+from . import call, MMBError
+
+THERMOSTATS = {"ConstantThermostat": 0, "InverseThermostat": 1, "LinearThermostat": 2,
+               "InverseSquareThermostat": 3, "SigmoidThermostat": 4}
+BRIDGES = {"UniformFlow": 0, "SchrodingerBridge": 1}
+ACT = {None: 0, "none": 0, "gelu": 1, "lrelu": 2}
+SEG_ROW, SEG_JET, SEG_JET_MASK = 0, 1, 2
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise MMBError(f"{name}: expected a tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise MMBError(f"{name}: tensor lives on {t.device}; the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise MMBError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise MMBError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def f32(t, name="tensor"):
+    return _chk(t, torch.float32, name)
+
+
+def i64(t, name="tensor"):
+    return _chk(t, torch.int64, name)
+
+
+def i32(t, name="tensor"):
+    return _chk(t, torch.int32, name)
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _fl(v):
+    return C.c_float(float(v))
+
+
+# ------------------------------------------------------------------------ masks / source
+class MaskInfo:
+    """Canonical per-batch mask data: maskf (B,N) f32, counts (B) i32, total (1) i32."""
+    __slots__ = ("maskf", "counts", "total", "B", "N")
+
+    def __init__(self, maskf, counts, total):
+        self.maskf, self.counts, self.total = maskf, counts, total
+        self.B, self.N = maskf.shape
+
+
+def mask_prepare(mask):
+    """mask: (B,N,1) or (B,N), int64 or float32."""
+    if mask.dim() == 3:
+        mask = mask.squeeze(-1)
+    B, N = mask.shape
+    if mask.dtype not in (torch.int64, torch.float32):
+        mask = mask.to(torch.int64)
+    mask = mask.contiguous()
+    dev = mask.device
+    maskf = torch.empty(B, N, dtype=torch.float32, device=dev)
+    counts = torch.empty(B, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    is64 = mask.dtype == torch.int64
+    ptr = i64(mask, "mask") if is64 else f32(mask, "mask")
+    call("mmb_mask_prepare", B, N, ptr, int(is64), f32(maskf), i32(counts), i32(total), stream())
+    return MaskInfo(maskf, counts, total)
+
+
+def source_uniform(B, N, Dc, V, device, pmf=None, sample_masks=False, seed=0, offset=0,
+                   want_x=True, want_k=True):
+    x0 = torch.empty(B, N, Dc, dtype=torch.float32, device=device) if want_x else None
+    k0 = torch.empty(B, N, 1, dtype=torch.int64, device=device) if want_k else None
+    mask = torch.empty(B, N, 1, dtype=torch.int64, device=device)
+    maskf = torch.empty(B, N, dtype=torch.float32, device=device)
+    counts = torch.empty(B, dtype=torch.int32, device=device)
+    npmf = 0 if pmf is None else pmf.numel()
+    call("mmb_source_uniform", B, N, Dc, V, int(bool(sample_masks)), f32(pmf, "pmf"), npmf, seed, offset,
+         f32(x0), i64(k0), i64(mask), f32(maskf), i32(counts), stream())
+    return x0, k0, mask, maskf, counts
+
+
+# ------------------------------------------------------------------------ K-A
+def bridge_sample(t_u, eps, x0, x1, z, k0, k1, u, bridge_kind, sigma, thermo_kind, gamma, V):
+    ref = x1 if x1 is not None else k1
+    B, N = ref.shape[0], ref.shape[1]
+    Dc = x1.shape[2] if x1 is not None else 0
+    dev = ref.device
+    t_out = torch.empty(B, dtype=torch.float32, device=dev)
+    xt = torch.empty_like(x1) if x1 is not None else None
+    kt = torch.empty_like(k1) if k1 is not None else None
+    call("mmb_bridge_sample", B, N, Dc, V, f32(t_u, "t_u"), _fl(eps), f32(x0, "x0"), f32(x1, "x1"), f32(z, "z"),
+         i64(k0, "k0"), i64(k1, "k1"), f32(u, "u"), bridge_kind, _fl(sigma or 0.0), thermo_kind, _fl(gamma or 0.0),
+         f32(t_out), f32(xt), i64(kt), stream())
+    return t_out, xt, kt
+
+
+def bridge_sample_rng(eps, x1, k1, bridge_kind, sigma, thermo_kind, gamma, V, seed, offset):
+    ref = x1 if x1 is not None else k1
+    B, N = ref.shape[0], ref.shape[1]
+    Dc = x1.shape[2] if x1 is not None else 0
+    dev = ref.device
+    t_out = torch.empty(B, dtype=torch.float32, device=dev)
+    x0 = torch.empty_like(x1) if x1 is not None else None
+    xt = torch.empty_like(x1) if x1 is not None else None
+    k0 = torch.empty_like(k1) if k1 is not None else None
+    kt = torch.empty_like(k1) if k1 is not None else None
+    call("mmb_bridge_sample_rng", B, N, Dc, V, _fl(eps), f32(x1, "x1"), i64(k1, "k1"), bridge_kind,
+         _fl(sigma or 0.0), thermo_kind, _fl(gamma or 0.0), seed, offset, f32(t_out), f32(x0), i64(k0), f32(xt),
+         i64(kt), stream())
+    return t_out, x0, k0, xt, kt
+
+
+def telegraph_probs(t, k0, k1, thermo_kind, gamma, V):
+    B, N = k0.shape[0], k0.shape[1]
+    probs = torch.empty(B, N, V, dtype=torch.float32, device=k0.device)
+    call("mmb_telegraph_probs", B, N, V, f32(t, "t"), i64(k0, "k0"), i64(k1, "k1"), thermo_kind, _fl(gamma),
+         f32(probs), stream())
+    return probs
+
+
+def bridge_drift(t, xt, x0, x1, bridge_kind):
+    B, N, Dc = xt.shape
+    out = torch.empty_like(xt)
+    call("mmb_bridge_drift", B, N, Dc, f32(t, "t"), f32(xt, "xt"), f32(x0, "x0"), f32(x1, "x1"), bridge_kind,
+         f32(out), stream())
+    return out
+
+
+# ------------------------------------------------------------------------ K-B
+def euler_step_(x, v, dt):
+    call("mmb_euler_step", x.numel(), f32(x, "x"), f32(v, "v"), _fl(dt), stream())
+    return x
+
+
+def euler_maruyama_step_(x, v, dt, t, t_scalar, sigma, dW=None, seed=0, offset=0):
+    B, N, Dc = x.shape
+    call("mmb_euler_maruyama_step", B, N, Dc, f32(x, "x"), f32(v, "v"), _fl(dt), f32(t, "t"), _fl(t_scalar),
+         _fl(sigma), f32(dW, "dW"), seed, offset, stream())
+    return x
+
+
+# ------------------------------------------------------------------------ K-C
+def telegraph_rate(logits, k, t, t_scalar, thermo_kind, gamma):
+    B, N, V = logits.shape
+    rates = torch.empty_like(logits)
+    call("mmb_telegraph_rate", B, N, V, f32(logits, "logits"), i64(k, "k"), f32(t, "t"), _fl(t_scalar), thermo_kind,
+         _fl(gamma), f32(rates), stream())
+    return rates
+
+
+def rate_tauleap_(logits, k, t, t_scalar, dt, thermo_kind, gamma, delta_n=None, seed=0, offset=0,
+                  overflow="wrap", final_argmax=False, rates_out=None):
+    B, N, V = logits.shape
+    call("mmb_rate_tauleap", B, N, V, f32(logits, "logits"), i64(k, "k"), f32(t, "t"), _fl(t_scalar), _fl(dt),
+         thermo_kind, _fl(gamma), f32(delta_n, "delta_n"), seed, offset, int(overflow == "clamp"),
+         int(bool(final_argmax)), f32(rates_out, "rates_out"), stream())
+    return k
+
+
+def rate_euler_jump_(logits, k, t, t_scalar, dt, thermo_kind, gamma, u=None, seed=0, offset=0,
+                     final_argmax=False, rates_out=None):
+    B, N, V = logits.shape
+    call("mmb_rate_euler_jump", B, N, V, f32(logits, "logits"), i64(k, "k"), f32(t, "t"), _fl(t_scalar), _fl(dt),
+         thermo_kind, _fl(gamma), f32(u, "u"), seed, offset, int(bool(final_argmax)), f32(rates_out, "rates_out"),
+         stream())
+    return k
+
+
+# ------------------------------------------------------------------------ K-F
+LOSS_WS = 2 * 1024
+
+
+def loss_fwd_bwd(head_c, head_d, t, xt, x0, x1, bridge_kind, k1, mi, vocab_freq, coef, want_grad=True):
+    ref = head_c if head_c is not None else head_d
+    B, N = ref.shape[0], ref.shape[1]
+    dev = ref.device
+    Dc = head_c.shape[2] if head_c is not None else 0
+    V = head_d.shape[2] if head_d is not None else 0
+    partials = torch.empty(LOSS_WS, dtype=torch.float32, device=dev)
+    losses = torch.empty(2, dtype=torch.float32, device=dev)
+    dc = torch.empty_like(head_c) if (want_grad and head_c is not None) else None
+    dd = torch.empty_like(head_d) if (want_grad and head_d is not None) else None
+    call("mmb_loss_fwd_bwd", B, N, Dc, V, f32(head_c, "head_c"), f32(head_d, "head_d"), f32(t, "t"), f32(xt, "xt"),
+         f32(x0, "x0"), f32(x1, "x1"), bridge_kind, i64(k1, "k1"), f32(mi.maskf), i32(mi.total),
+         f32(vocab_freq, "vocab_freq"), f32(coef, "coef"), f32(partials), f32(losses), f32(dc), f32(dd), stream())
+    return losses, dc, dd
+
+
+def _host2(w):
+    if w is None:
+        return None
+    return (C.c_float * 2)(float(w[0]), float(w[1]))
+
+
+def multimode_coef(s, fixed_w, device):
+    coef = torch.empty(2, dtype=torch.float32, device=device)
+    call("mmb_multimode_coef", f32(s, "loss_weights"), _host2(fixed_w), f32(coef), stream())
+    return coef
+
+
+def multimode_loss(losses, s, fixed_w):
+    loss = torch.empty(1, dtype=torch.float32, device=losses.device)
+    d_s = torch.empty(2, dtype=torch.float32, device=losses.device) if s is not None else None
+    call("mmb_multimode_loss", f32(losses), f32(s, "loss_weights"), _host2(fixed_w), f32(loss), f32(d_s), stream())
+    return loss, d_s
+
+
+# ------------------------------------------------------------------------ K-D / K-E
+def weight_norm(row_off, row_len, v_flat, g_flat, want_inv=False):
+    W = torch.empty_like(v_flat)
+    inv = torch.empty_like(g_flat) if want_inv else None
+    call("mmb_weight_norm", g_flat.numel(), i32(row_off), i32(row_len), f32(v_flat), f32(g_flat), f32(W), f32(inv),
+         stream())
+    return W, inv
+
+
+def weight_norm_bwd(row_off, row_len, v_flat, g_flat, inv, dW):
+    dv = torch.empty_like(v_flat)
+    dg = torch.empty_like(g_flat)
+    call("mmb_weight_norm_bwd", g_flat.numel(), i32(row_off), i32(row_len), f32(v_flat), f32(g_flat), f32(inv),
+         f32(dW), f32(dv), f32(dg), stream())
+    return dv, dg
+
+
+def linear_cat(segs, W, bias, rows_per_jet, maskf=None, act=None, residual=None, row_scale=None, out=None,
+               want_pre=False, w_ld=None, n_out=None):
+    """segs: list of (tensor2d, kind).  ROW tensors are (M,Ks) [row stride may exceed Ks];
+    JET tensors are (B,Ks).  W: (Nout,K) (or a column-sliced view described by w_ld)."""
+    n = len(segs)
+    M = None
+    ptrs = (C.c_void_p * n)()
+    widths = (C.c_int * n)()
+    kinds = (C.c_int * n)()
+    lds = (C.c_int * n)()
+    for i, (t, kind) in enumerate(segs):
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise MMBError("linear_cat: segments must be 2-D with unit inner stride")
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise MMBError("linear_cat: segments must be float32 HIP tensors (no CPU fallback)")
+        ptrs[i], widths[i], kinds[i], lds[i] = t.data_ptr(), t.shape[1], kind, t.stride(0)
+        if kind == SEG_ROW:
+            M = t.shape[0] if M is None else M
+            if t.shape[0] != M:
+                raise MMBError("linear_cat: ROW segments disagree on M")
+    if M is None:
+        raise MMBError("linear_cat: at least one ROW segment is required")
+    Nout = n_out if n_out is not None else W.shape[0]
+    wld = w_ld if w_ld is not None else W.stride(0)
+    if out is None:
+        out = torch.empty(M, Nout, dtype=torch.float32, device=segs[0][0].device)
+    pre = torch.empty(M, Nout, dtype=torch.float32, device=out.device) if want_pre else None
+    res_ld = residual.stride(0) if residual is not None else 0
+    call("mmb_linear_cat", M, rows_per_jet, n, ptrs, widths, kinds, lds, f32(maskf, "maskf"),
+         W.data_ptr(), wld, f32(bias, "bias"), Nout, ACT[act],
+         residual.data_ptr() if residual is not None else None, res_ld, f32(row_scale, "row_scale"),
+         out.data_ptr(), out.stride(0), f32(pre), stream())
+    return (out, pre) if want_pre else out
+
+
+def meansum_pool(x, mi, out=None):
+    """x: (B*N, H) rows (row stride may exceed H) -> pooled (B, 2H) = [mean, 0.01*sum]."""
+    B, N = mi.B, mi.N
+    H = x.shape[1]
+    if out is None:
+        out = torch.empty(B, 2 * H, dtype=torch.float32, device=x.device)
+    call("mmb_meansum_pool", B, N, H, x.data_ptr(), x.stride(0), f32(mi.maskf), i32(mi.counts), out.data_ptr(),
+         out.stride(0), stream())
+    return out
+
+
+def embed(t, t_scalar, x, k, mi, fourier_W, time_W, time_b, cont_W, cont_b, table):
+    B, N = mi.B, mi.N
+    dev = mi.maskf.device
+    Et = time_W.shape[0]
+    Dc = x.shape[-1] if x is not None else 0
+    Ec = cont_W.shape[0] if (x is not None) else 0
+    V, Ed = (table.shape if (k is not None) else (0, 0))
+    temb = torch.empty(B, Et, dtype=torch.float32, device=dev)
+    cont = torch.empty(B * N, Ec, dtype=torch.float32, device=dev) if x is not None else None
+    disc = torch.empty(B * N, Ed, dtype=torch.float32, device=dev) if k is not None else None
+    call("mmb_embed", B, N, Dc, V, Et, Ec, Ed, f32(t, "t"), _fl(t_scalar), f32(x, "x"), i64(k, "k"), f32(mi.maskf),
+         f32(fourier_W), f32(time_W), f32(time_b), f32(cont_W if x is not None else None),
+         f32(cont_b if x is not None else None), f32(table if k is not None else None), f32(temb), f32(cont),
+         f32(disc), stream())
+    return temb, cont, disc

@@ -189,7 +189,12 @@ int mmb_weight_norm_bwd(int n_rows, const int32_t* row_off, const int32_t* row_l
  * seg_kind (MMB_SEG_*), seg_ld (leading dimension in elements).  W is (Nout, K) row-major
  * with leading dimension w_ld (a column slice of a wider matrix is allowed).
  * pre_act (M,Nout) | NULL stores the pre-activation (needed by the GELU backward).
- * row_scale (M) | NULL multiplies the finished row. */
+ * row_scale (M) | NULL multiplies the finished row.
+ * Second-stage epilogue (EPiCLayer, epic.py:196-206 and the encoder skip :89-90):
+ *   Y1 = act(z) + residual            -> Y  (may be NULL when only Y2 is wanted)
+ *   Y2 = dropout(post_act(Y1)) + res2 -> Y2 (NULL to skip)
+ * dropout is the inverted form with a Philox keep-mask (seed, offset, element index);
+ * drop_p = 0 disables it. */
 int mmb_linear_cat(int M, int rows_per_jet, int n_seg,
                    const void* const* seg_ptr_host, const int* seg_width_host,
                    const int* seg_kind_host, const int* seg_ld_host,
@@ -197,7 +202,9 @@ int mmb_linear_cat(int M, int rows_per_jet, int n_seg,
                    const float* W, int64_t w_ld, const float* bias,
                    int Nout, int act, const float* residual, int64_t res_ld,
                    const float* row_scale,
-                   float* Y, int64_t y_ld, float* pre_act, void* stream);
+                   float* Y, int64_t y_ld, float* pre_act,
+                   int post_act, float drop_p, uint64_t seed, uint64_t offset,
+                   const float* res2, int64_t res2_ld, float* Y2, int64_t y2_ld, void* stream);
 
 /* EPiCEncoder._meansum_pool (epic.py:100-107) without the concat:
  * pooled[b, 0:H] = sum_n x*mask / counts[b] ; pooled[b, H:2H] = 0.01 * sum_n x*mask. */

@@ -27,6 +27,25 @@ struct Segs {
   int n;
 };
 
+// second-stage epilogue: Y2 = dropout(post_act(Y1)) + res2   (epic.py:196-206 + :89-90)
+struct Post {
+  float* Y2;
+  int64_t y2_ld;
+  const float* res2;
+  int64_t res2_ld;
+  int act;
+  float drop_p;
+  uint64_t seed, offset;
+};
+
+// inverted dropout with a Philox keep-mask indexed by the element (row*Nout+col)
+__device__ inline float dropout_apply(float v, float p, uint64_t seed, uint64_t offset, uint64_t idx) {
+  uint32_t r[4];
+  philox4(seed, offset, idx >> 2, 0xD0D0u, r);
+  const float u = u01(r[idx & 3]);
+  return u < p ? 0.0f : v / (1.0f - p);
+}
+
 __device__ inline float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ inline float apply_act(int act, float x) {
   if (act == MMB_ACT_GELU) return gelu_exact(x);
@@ -57,7 +76,7 @@ linear_cat_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restri
                   const float* __restrict__ W, int64_t w_ld, const float* __restrict__ bias, int Nout,
                   int act, const float* __restrict__ residual, int64_t res_ld,
                   const float* __restrict__ row_scale, float* __restrict__ Y, int64_t y_ld,
-                  float* __restrict__ pre_act) {
+                  float* __restrict__ pre_act, Post post) {
   constexpr int BN = NT * 32;
   constexpr int HALF = BK / 2;
   constexpr int PITCH = BK + 4;                 // conflict-free for ds_read_b128
@@ -204,7 +223,13 @@ linear_cat_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restri
       float y = apply_act(act, z);
       if (residual) y += residual[(int64_t)row * res_ld + col];
       if (row_scale) y *= row_scale[row];
-      Y[(int64_t)row * y_ld + col] = y;
+      if (Y) Y[(int64_t)row * y_ld + col] = y;
+      if (post.Y2) {
+        float y2 = apply_act(post.act, y);
+        if (post.drop_p > 0.0f) y2 = dropout_apply(y2, post.drop_p, post.seed, post.offset, (uint64_t)row * Nout + col);
+        if (post.res2) y2 += post.res2[(int64_t)row * post.res2_ld + col];
+        post.Y2[(int64_t)row * post.y2_ld + col] = y2;
+      }
     }
   }
 }
@@ -320,9 +345,10 @@ particle_embed_kernel(int P, int Dc, int Ec, int Ed, const float* __restrict__ x
 template <int WAVES, int NT, int BK, bool ALIGNED>
 static void launch_linear(dim3 grid, hipStream_t st, int M, int rpj, const Segs& sg, int K, const float* maskf,
                           const float* W, int64_t w_ld, const float* bias, int Nout, int act, const float* residual,
-                          int64_t res_ld, const float* row_scale, float* Y, int64_t y_ld, float* pre_act) {
+                          int64_t res_ld, const float* row_scale, float* Y, int64_t y_ld, float* pre_act,
+                          const Post& post) {
   hipLaunchKernelGGL((linear_cat_kernel<WAVES, NT, BK, ALIGNED>), grid, dim3(WAVES * 64), 0, st, M, rpj, sg, K,
-                     maskf, W, w_ld, bias, Nout, act, residual, res_ld, row_scale, Y, y_ld, pre_act);
+                     maskf, W, w_ld, bias, Nout, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);
 }
 
 }  // namespace mmb
@@ -333,11 +359,16 @@ extern "C" int mmb_linear_cat(int M, int rows_per_jet, int n_seg, const void* co
                               const int* seg_kind, const int* seg_ld, const float* maskf, const float* W,
                               int64_t w_ld, const float* bias, int Nout, int act, const float* residual,
                               int64_t res_ld, const float* row_scale, float* Y, int64_t y_ld, float* pre_act,
-                              void* stream) {
+                              int post_act, float drop_p, uint64_t seed, uint64_t offset, const float* res2,
+                              int64_t res2_ld, float* Y2, int64_t y2_ld, void* stream) {
   MMB_REQUIRE(M > 0 && Nout > 0, "mmb_linear_cat: empty shape M=%d Nout=%d", M, Nout);
+  MMB_REQUIRE(Y || Y2, "mmb_linear_cat: no output given");
+  MMB_REQUIRE(post_act >= 0 && post_act <= 2, "mmb_linear_cat: bad post activation %d", post_act);
+  MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_linear_cat: dropout p=%f outside [0,1)", drop_p);
+  Post post{Y2, y2_ld, res2, res2_ld, post_act, drop_p, seed, offset};
   MMB_REQUIRE(rows_per_jet > 0, "mmb_linear_cat: rows_per_jet must be > 0");
   MMB_REQUIRE(n_seg >= 1 && n_seg <= 4, "mmb_linear_cat: n_seg=%d outside [1,4]", n_seg);
-  MMB_REQUIRE(seg_ptr && seg_width && seg_kind && seg_ld && W && Y, "mmb_linear_cat: NULL argument");
+  MMB_REQUIRE(seg_ptr && seg_width && seg_kind && seg_ld && W, "mmb_linear_cat: NULL argument");
   MMB_REQUIRE(act >= 0 && act <= 2, "mmb_linear_cat: bad activation %d", act);
   Segs sg;
   sg.n = n_seg;
@@ -369,7 +400,7 @@ extern "C" int mmb_linear_cat(int M, int rows_per_jet, int n_seg, const void* co
   dim3 grid((M + bm - 1) / bm, (Nout + nt * 32 - 1) / (nt * 32));
 #define MMB_LAUNCH(WV, NT_, BK_, AL)                                                                           \
   launch_linear<WV, NT_, BK_, AL>(grid, st, M, rows_per_jet, sg, K, maskf, W, w_ld, bias, Nout, act, residual, \
-                                  res_ld, row_scale, Y, y_ld, pre_act)
+                                  res_ld, row_scale, Y, y_ld, pre_act, post)
 #define MMB_PICK_NT(WV, BK_, AL)                \
   do {                                          \
     if (nt == 1) MMB_LAUNCH(WV, 1, BK_, AL);    \

@@ -232,9 +232,11 @@ def weight_norm_bwd(row_off, row_len, v_flat, g_flat, inv, dW):
 
 
 def linear_cat(segs, W, bias, rows_per_jet, maskf=None, act=None, residual=None, row_scale=None, out=None,
-               want_pre=False, w_ld=None, n_out=None):
-    """segs: list of (tensor2d, kind).  ROW tensors are (M,Ks) [row stride may exceed Ks];
-    JET tensors are (B,Ks).  W: (Nout,K) (or a column-sliced view described by w_ld)."""
+               want_pre=False, post=None, res2=None, out2=None, want_y1=True, drop_p=0.0, seed=0, offset=0):
+    """Y1 = act(cat(segs) @ W^T + b) + residual ; optional Y2 = dropout(post(Y1)) + res2.
+    segs: list of (tensor2d, kind).  ROW tensors are (M,Ks) [row stride may exceed Ks];
+    JET tensors are (B,Ks).  W: (Nout,K), row stride may exceed K (column slice).
+    Returns Y1, or (Y1, Y2) when a second stage is requested, with `pre` appended if want_pre."""
     n = len(segs)
     M = None
     ptrs = (C.c_void_p * n)()
@@ -253,17 +255,31 @@ def linear_cat(segs, W, bias, rows_per_jet, maskf=None, act=None, residual=None,
                 raise MMBError("linear_cat: ROW segments disagree on M")
     if M is None:
         raise MMBError("linear_cat: at least one ROW segment is required")
-    Nout = n_out if n_out is not None else W.shape[0]
-    wld = w_ld if w_ld is not None else W.stride(0)
-    if out is None:
-        out = torch.empty(M, Nout, dtype=torch.float32, device=segs[0][0].device)
-    pre = torch.empty(M, Nout, dtype=torch.float32, device=out.device) if want_pre else None
-    res_ld = residual.stride(0) if residual is not None else 0
+    if W.dim() != 2 or W.stride(1) != 1 or not W.is_cuda or W.dtype != torch.float32:
+        raise MMBError("linear_cat: W must be a 2-D float32 HIP tensor with unit inner stride")
+    Nout = W.shape[0]
+    dev = segs[0][0].device
+    two = post is not None or res2 is not None or out2 is not None
+    if out is None and (want_y1 or not two):
+        out = torch.empty(M, Nout, dtype=torch.float32, device=dev)
+    if two and out2 is None:
+        out2 = torch.empty(M, Nout, dtype=torch.float32, device=dev)
+    pre = torch.empty(M, Nout, dtype=torch.float32, device=dev) if want_pre else None
+
+    def p2(t):
+        return (t.data_ptr(), t.stride(0)) if t is not None else (None, 0)
+
+    rp, rl = p2(residual)
+    op, ol = p2(out)
+    r2p, r2l = p2(res2)
+    o2p, o2l = p2(out2)
     call("mmb_linear_cat", M, rows_per_jet, n, ptrs, widths, kinds, lds, f32(maskf, "maskf"),
-         W.data_ptr(), wld, f32(bias, "bias"), Nout, ACT[act],
-         residual.data_ptr() if residual is not None else None, res_ld, f32(row_scale, "row_scale"),
-         out.data_ptr(), out.stride(0), f32(pre), stream())
-    return (out, pre) if want_pre else out
+         W.data_ptr(), W.stride(0), f32(bias, "bias"), Nout, ACT[act], rp, rl, f32(row_scale, "row_scale"),
+         op, ol, f32(pre), ACT[post], _fl(drop_p), seed, offset, r2p, r2l, o2p, o2l, stream())
+    res = (out, out2) if two else out
+    if want_pre:
+        res = (res + (pre,)) if two else (res, pre)
+    return res
 
 
 def meansum_pool(x, mi, out=None):

@@ -1,0 +1,301 @@
+"""MultiModalBridgeMatching: hybrid continuous/discrete bridge matching on MI355X.
+
+Same constructor (ExperimentConfigs), registries, attribute names and step methods as the
+reference (model/multimodal_bridge_matching.py), minus Lightning: this is a plain nn.Module
+driven by pipeline/experiment.py.  What runs underneath:
+
+  training_step : mmb_bridge_sample_rng (K-A) -> embedder + EPiC encoder (K-D/K-E, taped)
+                  -> mmb_loss_fwd_bwd (K-F: losses AND d loss/d heads in one pass)
+                  -> MultiModeLoss kernel; the backward replays the tape (encoders/backward.py)
+  predict_step  : SourceUniform kernel -> simulate_dynamics: per step [encoder -> K-B]
+                  [encoder -> K-C], zero host syncs, final k = argmax of the last rates.
+
+Everything returned is a DEVICE tensor; nothing calls .item().
+"""
+from typing import Dict
+
+import torch
+from torch import nn
+
+from pipeline.registry import registered_distributions as Distribution
+from pipeline.registry import registered_models as Encoder
+from pipeline.registry import registered_bridges as Bridge
+from pipeline.registry import registered_optimizers as Optimizer
+from pipeline.registry import registered_schedulers as Scheduler
+from pipeline.registry import registered_thermostats as Thermostat
+
+from tensorclass import TensorMultiModal
+from datamodules.datasets import DataCoupling
+from encoders.embedder import MultiModalEmbedder
+from model.solvers import ContinuousSolver, DiscreteSolver
+from mmb_hip import ops
+
+
+class MultiModeLoss(nn.Module):
+    """Fixed weights, or learnable uncertainty weights s: sum_i 0.5*exp(-s_i)*L_i + 0.5*s_i."""
+
+    def __init__(self, weights=None):
+        super().__init__()
+        weights = [1.0, 1.0] if weights == "fixed" or weights is None else weights
+        if weights == "learnable":
+            self.learnable = True
+            self.loss_weights = nn.Parameter(torch.tensor([0.0, 0.0]))
+        else:
+            self.learnable = False
+            self.loss_weights = torch.tensor([float(w) for w in weights])
+
+    def _s(self):
+        return self.loss_weights.detach() if self.learnable else None
+
+    def _fixed(self):
+        return None if self.learnable else self.loss_weights.tolist()
+
+    def coef(self, device):
+        """d loss / d L_i as a device tensor (2,)."""
+        return ops.multimode_coef(self._s(), self._fixed(), device)
+
+    def combine(self, losses):
+        """losses (2,) device tensor -> (loss (1,), d_s (2,) | None)."""
+        return ops.multimode_loss(losses, self._s(), self._fixed())
+
+    def forward(self, losses):
+        stacked = losses if isinstance(losses, torch.Tensor) else torch.stack([l.reshape(()) for l in losses])
+        return self.combine(stacked.contiguous().float())[0][0]
+
+    def weight_vals(self):
+        """Device tensor of the two effective weights (upstream returns python floats via .item(),
+        a host sync per step)."""
+        if self.learnable:
+            return torch.exp(-self.loss_weights.detach())
+        return self.loss_weights
+
+
+class MultiModalBridgeMatching(nn.Module):
+    """Bridge-matching model for multi-modal particle clouds."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.embedder = MultiModalEmbedder(config)
+        self.encoder = Encoder[config.encoder.name](config)
+        self.modality = config.data.modality
+        self.vocab_size = config.data.vocab_size
+
+        if self.modality in ("continuous", "multi-modal"):
+            self.bridge_continuous = Bridge[config.model.bridge_continuous](sigma=config.model.sigma)
+        if self.modality in ("discrete", "multi-modal"):
+            thermostat = Thermostat[config.model.thermostat_fn](config.model.gamma, self.vocab_size)
+            self.bridge_discrete = Bridge[config.model.bridge_discrete](
+                gamma=config.model.gamma, vocab_size=self.vocab_size, thermostat_fn=thermostat)
+            self.vocab_freq = config.data.vocab_freq
+        self._freq_dev = None
+        self.loss_multimode = MultiModeLoss(weights=config.model.loss_weights)
+        self.path_snapshots_idx = config.model.save_path_history_snapshots
+        if not config.data.source_path:
+            self.sample_source = Distribution[config.data.source_name](config)
+        if not config.data.target_path:
+            self.sample_target = Distribution[config.data.target_name](config)
+        self.seed = int(getattr(config, "seed", 0xA0A0))
+        self.rank = 0
+        self._calls = 0
+        self._tape = None
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def manual_seed(self, seed, rank=0):
+        """Philox key (seed) and stream (rank) of every in-kernel draw."""
+        self.seed, self.rank, self._calls = int(seed), int(rank), 0
+        if hasattr(self, "sample_source"):
+            self.sample_source.manual_seed(seed ^ (rank * 0x9E3779B1), 0)
+
+    def _next_offset(self):
+        self._calls += 1
+        return (self.rank << 48) + (self._calls << 8)
+
+    def _mask_info(self, state):
+        mi = getattr(state, "_mask_info", None)
+        if mi is None or mi.total is None and self._tape is not None:
+            mi = ops.mask_prepare(state.mask)
+            state._mask_info = mi
+        return mi
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, state: TensorMultiModal, batch: DataCoupling = None) -> TensorMultiModal:
+        return self.forward_heads(state, batch, which="both")
+
+    def forward_heads(self, state, batch=None, which="both"):
+        """Embedder + encoder.  `which` names the head the caller consumes; the generic layered
+        path always evaluates both (the fused generation kernel honours it)."""
+        mi = self._mask_info(state)
+        t = getattr(state, "_t_scalar", None)
+        time = state.time if t is None else t
+        loc = self.embedder.embed(time, state.continuous, state.discrete, state.mask, mi=mi, tape=self._tape)
+        glob = TensorMultiModal(time=loc.temb)
+        off = self._next_offset() if (self.training and self.config.encoder.dropout) else 0
+        return self.encoder(loc, glob, tape=self._tape, seed=self.seed, offset0=off)
+
+    # ------------------------------------------------------------------ training
+    def sample_bridges(self, batch: DataCoupling, noise: Dict[str, torch.Tensor] = None) -> TensorMultiModal:
+        """Sample the stochastic bridges at a random per-jet time.
+
+        Fast path (no source given, SourceUniform): ONE fused Philox kernel draws t, the source
+        (x0,k0), z and the categorical uniform and writes x_t, k_t (and x0 for the drift target).
+        Otherwise / with `noise` = {"t_u","z","u_k"}: the injected-noise kernel."""
+        eps = self.config.model.time_eps
+        tgt = batch.target
+        B, N = tgt.shape[0], tgt.shape[1]
+        dev = tgt.mask.device
+        has_c, has_d = tgt.has_continuous, tgt.has_discrete
+        bc = self.bridge_continuous.kind if has_c else 0
+        sigma = self.bridge_continuous.sigma if has_c else 0.0
+        tk = self.bridge_discrete.thermo_kind if has_d else 0
+        gamma = self.bridge_discrete.gamma if has_d else 0.0
+        x1 = tgt.continuous.contiguous() if has_c else None
+        k1 = tgt.discrete.contiguous() if has_d else None
+        fused_ok = (not batch.has_source and noise is None and hasattr(self, "sample_source")
+                    and type(self.sample_source).__name__ == "SourceUniform")
+        if fused_ok:
+            t, x0, k0, xt, kt = ops.bridge_sample_rng(eps, x1, k1, bc, sigma, tk, gamma, self.vocab_size,
+                                                      self.seed, self._next_offset())
+            batch.source = TensorMultiModal(None, x0, k0, torch.ones_like(tgt.mask))
+        else:
+            if not batch.has_source:
+                batch.source = self.sample_source(shape=tgt.shape, device=dev)
+            noise = noise or {}
+            t_u = noise["t_u"] if "t_u" in noise else torch.rand(B, device=dev)
+            z = (noise["z"] if "z" in noise else torch.randn_like(x1)) if has_c else None
+            u = (noise["u_k"] if "u_k" in noise else torch.rand(B, N, device=dev)) if has_d else None
+            src = batch.source
+            t, xt, kt = ops.bridge_sample(t_u.contiguous(), eps,
+                                          src.continuous.contiguous() if has_c else None, x1,
+                                          z.contiguous() if has_c else None,
+                                          src.discrete.contiguous() if has_d else None, k1,
+                                          u.contiguous() if has_d else None, bc, sigma, tk, gamma, self.vocab_size)
+        return TensorMultiModal(t.view(B, 1, 1), xt, kt, tgt.mask)
+
+    def _freq(self, dev):
+        freq = getattr(self, "vocab_freq", None)
+        if not freq:
+            return None
+        if self._freq_dev is None or self._freq_dev.device != dev:
+            self._freq_dev = torch.tensor(freq, dtype=torch.float32, device=dev)
+        return self._freq_dev
+
+    def _loss_kernel(self, heads, state, batch, want_grad):
+        mi = self._mask_info(state)
+        if mi.total is None:
+            mi = ops.mask_prepare(state.mask)
+        hc = heads.continuous.contiguous() if heads.has_continuous else None
+        hd = heads.discrete.contiguous() if heads.has_discrete else None
+        B = state.mask.shape[0]
+        dev = state.mask.device
+        coef = self.loss_multimode.coef(dev)
+        args_c = (None, None, None, None)
+        bk = 0
+        if hc is not None:
+            bk = self.bridge_continuous.kind
+            args_c = (state.time.reshape(B, -1)[:, 0].contiguous(), state.continuous.contiguous(),
+                      batch.source.continuous.contiguous(), batch.target.continuous.contiguous())
+        k1 = batch.target.discrete.contiguous() if hd is not None else None
+        return ops.loss_fwd_bwd(hc, hd, *args_c, bk, k1, mi, self._freq(dev) if hd is not None else None, coef,
+                                want_grad=want_grad)
+
+    def loss_fn(self, heads: TensorMultiModal, state: TensorMultiModal, batch: DataCoupling):
+        """(loss_continuous, loss_discrete): masked MSE against the bridge drift and masked
+        (frequency-weighted) cross-entropy; both divided by the particle count sum(mask)."""
+        losses, _, _ = self._loss_kernel(heads, state, batch, want_grad=False)
+        return losses[0], losses[1]
+
+    def _step(self, batch, prefix, train):
+        state = self.sample_bridges(batch)
+        self._tape = [] if train else None
+        try:
+            heads = self.forward(state, batch)
+            losses, d_hc, d_hd = self._loss_kernel(heads, state, batch, want_grad=train)
+            loss, d_s = self.loss_multimode.combine(losses)
+            tape = self._tape
+        finally:
+            self._tape = None
+        weights = self.loss_multimode.weight_vals()
+        out = {("loss" if train else "val_loss"): loss[0],
+               f"{prefix}_loss_continuous": losses[0], f"{prefix}_loss_discrete": losses[1],
+               f"{prefix}_weights_continuous": weights[0], f"{prefix}_weights_discrete": weights[1]}
+        if train:
+            from encoders.backward import attach_backward
+            out["loss"] = attach_backward(self, loss, tape, heads, d_hc, d_hd, d_s)
+        return out
+
+    def training_step(self, batch: DataCoupling, batch_idx=0) -> Dict[str, torch.Tensor]:
+        return self._step(batch, "train", True)
+
+    def validation_step(self, batch: DataCoupling, batch_idx=0) -> Dict[str, torch.Tensor]:
+        with torch.no_grad():
+            return self._step(batch, "val", False)
+
+    def configure_optimizers(self):
+        tr = self.config.trainer
+        optimizer = Optimizer[tr.optimizer_name](self.parameters(), **tr.optimizer_params)
+        if tr.scheduler_name:
+            return [optimizer], [Scheduler[tr.scheduler_name](optimizer, **tr.scheduler_params)]
+        return optimizer
+
+    # ------------------------------------------------------------------ generation
+    @torch.no_grad()
+    def predict_step(self, batch: DataCoupling, batch_idx=0, to_cpu=True):
+        """Generate target data from the source by integrating the learned dynamics.
+        Returns (paths, target_state); paths has leading dim 2 = (source, generated)."""
+        dev = self.device
+        if not batch.has_source:
+            batch.source = self.sample_source(shape=batch.target.shape, device=dev, sample_masks=True)
+        src = batch.source
+        source_state = TensorMultiModal(torch.zeros_like(src.mask), src.continuous, src.discrete, src.mask)
+        if hasattr(src, "_mask_info"):
+            source_state._mask_info = src._mask_info
+        tgt = batch.target
+        target_state = TensorMultiModal(torch.ones_like(src.mask), tgt.continuous, tgt.discrete, tgt.mask)
+        paths = self.simulate_dynamics(source_state, batch)
+        if to_cpu:
+            return paths.detach().cpu(), target_state.detach().cpu()
+        return paths, target_state
+
+    @torch.no_grad()
+    def simulate_dynamics(self, state: TensorMultiModal, batch: DataCoupling, noise=None) -> TensorMultiModal:
+        """Euler / Euler-Maruyama drift steps interleaved with tau-leap (or Euler) jumps over the
+        fp32 grid linspace(eps, 1-eps, steps); ALL grid points are stepped and the final
+        discrete state is argmax_v of the last step's rates, exactly as upstream (:227-259)."""
+        cfg = self.config.model
+        eps, steps = cfg.time_eps, cfg.num_timesteps
+        grid = torch.linspace(eps, 1.0 - eps, steps)                  # host fp32, as torch.linspace
+        delta_t = float((grid[-1] - grid[0]) / (len(grid) - 1))
+        times = [float(v) for v in grid.tolist()]
+        solver_c = ContinuousSolver(self.config, model=self)
+        solver_d = DiscreteSolver(self.config, model=self)
+        call_id = self._next_offset() >> 8
+        for s in (solver_c, solver_d):
+            s.noise, s.seed, s.stream_id = noise, self.seed, call_id & 0xFFFFF
+        first = state.clone()
+        if state.has_discrete:
+            state.discrete = state.discrete.clone()                   # the source tokens stay intact
+        mi = self._mask_info(state)
+        was_training = self.training
+        self.eval()
+        rates = None
+        for i, t in enumerate(times):
+            state._t_scalar = t
+            solver_c.step = solver_d.step = i
+            solver_d.final = (i == len(times) - 1)
+            state = solver_c.fwd_step(state, batch, delta_t)
+            state, rates = solver_d.fwd_step(state, batch, delta_t)
+        self.train(was_training)
+        B, N = mi.B, mi.N
+        state.time = torch.full((B, N, 1), times[-1], device=state.mask.device)
+        state._t_scalar = None
+        return TensorMultiModal.stack([first, state], dim=0)
+
+    def reshape_time_dim_like(self, t, state):
+        if isinstance(t, (float, int)):
+            return t
+        return t.reshape(-1, *([1] * (state.ndim - 1)))

@@ -1,0 +1,31 @@
+"""Name -> class registries: the plug-in boundary the model constructor looks classes up in
+(reference: pipeline/registry.py:9-55).  Same dict names and keys; the values are the
+HIP-backed classes of this package, so an existing YAML is a drop-in."""
+import torch
+
+from distributions.noise import SourceUniform
+from model.bridges import UniformFlow, SchrodingerBridge, TelegraphBridge
+from model.thermostats import (ConstantThermostat, InverseThermostat, LinearThermostat, InverseSquareThermostat,
+                               SigmoidThermostat)
+from encoders.multimodal_epic import UniModalEPiC, MultiModalEPiC
+
+registered_datasets = {}          # AspenOpenJets HDF5 reader: outside the hot path
+
+registered_distributions = {"SourceUniform": SourceUniform}
+
+registered_bridges = {"UniformFlow": UniformFlow, "SchrodingerBridge": SchrodingerBridge,
+                      "TelegraphBridge": TelegraphBridge}
+
+registered_models = {"UniModalEPiC": UniModalEPiC, "MultiModalEPiC": MultiModalEPiC}
+
+registered_thermostats = {"ConstantThermostat": ConstantThermostat, "LinearThermostat": LinearThermostat,
+                          "InverseThermostat": InverseThermostat,
+                          "InverseSquareThermostat": InverseSquareThermostat,
+                          "SigmoidThermostat": SigmoidThermostat}
+
+registered_optimizers = {"Adam": torch.optim.Adam, "AdamW": torch.optim.AdamW}
+
+registered_schedulers = {"StepLR": torch.optim.lr_scheduler.StepLR,
+                         "ReduceLROnPlateau": torch.optim.lr_scheduler.ReduceLROnPlateau,
+                         "CosineAnnealingLR": torch.optim.lr_scheduler.CosineAnnealingLR,
+                         "OneCycleLR": torch.optim.lr_scheduler.OneCycleLR}

@@ -16,7 +16,7 @@ import torch
 AOJ_TOKEN_FREQ = [0.304, 0.0847, 0.2986, 0.3078, 0.0013, 0.0014, 0.0011, 0.001]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-PMF_FILE = os.path.join(_HERE, "..", "tests", "golden", "aoj_multiplicity_pmf.json")
+PMF_FILE = os.path.join(_HERE, "..", "tests", "golden", "metadata.json")
 
 
 def _rng(seed, name):

@@ -196,6 +196,22 @@ def test_linear_cat(ops, M, N, widths, kinds, Nout, act):
     out, pre = ops.linear_cat(segs, dev(W), dev(b), N, maskf=dev(mask), act=act, residual=dev(res), want_pre=True)
     close(pre, z, rtol=1e-4, atol=2e-5)
     close(out, y, rtol=1e-4, atol=2e-5)
+    # second-stage epilogue: y2 = lrelu(y1) + res2, written into a column slice of a wider buffer
+    res2 = torch.randn(M, Nout, generator=g)
+    wide = torch.zeros(M, Nout + 8, device="cuda")
+    y1, y2 = ops.linear_cat(segs, dev(W), dev(b), N, maskf=dev(mask), act=act, residual=dev(res), post="lrelu",
+                            res2=dev(res2), out2=wide[:, 8:])
+    close(y1, y, rtol=1e-4, atol=2e-5)
+    close(y2, torch.nn.functional.leaky_relu(y) + res2, rtol=1e-4, atol=2e-5)
+    assert float(wide[:, :8].abs().sum()) == 0.0
+    # dropout keep-rate and scaling
+    _, yd = ops.linear_cat(segs, dev(W), dev(b), N, maskf=dev(mask), act=act, residual=dev(res), post="lrelu",
+                           drop_p=0.25, seed=3, offset=9, want_y1=False)
+    ref2 = torch.nn.functional.leaky_relu(y)
+    kept = yd.cpu() != 0
+    if M * Nout > 2000:
+        assert abs(kept.float().mean().item() - 0.75) < 0.05
+    close(yd.cpu()[kept], (ref2 / 0.75)[kept], rtol=1e-4, atol=3e-5)
 
 
 def test_pool_embed_weightnorm(ops, golden):

@@ -1,0 +1,149 @@
+"""GPU parity of the drop-in classes (same names / signatures as the reference) against the
+golden vectors of the imported reference: bridge sampling, embedder, encoder heads, losses,
+parameter gradients and the full generation loop under injected noise.
+Bar (north_star): jump-state indices bit-exact; continuous features / losses rtol 1e-4 in fp32."""
+import copy
+
+import pytest
+import torch
+
+from conftest import GOLDEN, MODEL_GOLDENS
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    torch.testing.assert_close(a.detach().cpu().float(), b.detach().cpu().float(), rtol=rtol, atol=atol)
+
+
+def build(g, **model_updates):
+    from pipeline.configs import ExperimentConfigs
+    from model.multimodal_bridge_matching import MultiModalBridgeMatching
+    cfg = copy.deepcopy(g.cfg)
+    cfg["data"]["target_path"] = GOLDEN            # metadata.json (multiplicity pmf) lives there
+    cfg["model"].update(model_updates)
+    config = ExperimentConfigs(cfg)
+    model = MultiModalBridgeMatching(config)
+    missing = model.load_state_dict(g.params, strict=True)       # reference parameter names (Appendix B)
+    return model.cuda().eval()
+
+
+def batch_of(g, with_source=True):
+    from tensorclass import TensorMultiModal
+    from datamodules.datasets import DataCoupling
+    t = g.t
+    c = lambda a: None if a is None else a.cuda()
+    tgt = TensorMultiModal(None, c(t.get("x1")), c(t["k1"]), c(t["mask"]))
+    src = TensorMultiModal(None, c(t.get("x0")), c(t["k0"]), torch.ones_like(c(t["mask"]))) if with_source else TensorMultiModal()
+    return DataCoupling(src, tgt, None)
+
+
+@pytest.mark.parametrize("name", MODEL_GOLDENS)
+def test_sample_bridges_injected(golden, name):
+    g = golden(name)
+    model = build(g)
+    t = g.t
+    noise = {"t_u": t["t_u"].cuda(), "u_k": t["u_k"].cuda()}
+    if "z" in t:
+        noise["z"] = t["z"].cuda()
+    st = model.sample_bridges(batch_of(g), noise=noise)
+    assert st.time.shape == t["time"].shape and st.time.dim() == 3
+    close(st.time, t["time"], rtol=1e-6, atol=1e-7)
+    if "xt" in t:
+        close(st.continuous, t["xt"], rtol=1e-5, atol=1e-6)
+    ok = t["u_k_margin"] > 1e-5
+    assert st.discrete.shape == t["kt"].shape and st.discrete.dtype == torch.int64
+    assert torch.equal(st.discrete.cpu().squeeze(-1)[ok], t["kt"].squeeze(-1)[ok])
+
+
+@pytest.mark.parametrize("name", MODEL_GOLDENS)
+def test_embedder_encoder_heads(golden, name):
+    from tensorclass import TensorMultiModal
+    g = golden(name)
+    model = build(g)
+    t = g.t
+    c = lambda a: None if a is None else a.cuda()
+    state = TensorMultiModal(c(t["time"]), c(t.get("xt")), c(t["kt"]), c(t["mask"]))
+    loc, glob = model.embedder(state, None)
+    close(glob.time, t["cap:emb.glob_time"], rtol=1e-4, atol=2e-5)
+    close(loc.time, t["cap:emb.time"], rtol=1e-4, atol=2e-5)
+    if "cap:emb.continuous" in t:
+        close(loc.continuous, t["cap:emb.continuous"])
+    assert loc.discrete.dtype == torch.int64                                  # quirk Q1
+    assert torch.equal(loc.discrete.cpu(), t["cap:emb.discrete"])
+    heads = model(state, None)
+    if "head_continuous" in t:
+        close(heads.continuous, t["head_continuous"], rtol=1e-4, atol=2e-5)
+    close(heads.discrete, t["head_discrete"], rtol=1e-4, atol=2e-5)
+    # reference-style call with materialised (B,N,*) tensors goes through the generic segment path
+    plain = TensorMultiModal(loc.time.clone(), None if loc.continuous is None else loc.continuous.clone(),
+                             loc.discrete.clone(), loc.mask)
+    heads2 = model.encoder(plain, glob)
+    close(heads2.discrete, t["head_discrete"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", MODEL_GOLDENS)
+def test_loss_values(golden, name):
+    from tensorclass import TensorMultiModal
+    g = golden(name)
+    model = build(g)
+    t = g.t
+    c = lambda a: None if a is None else a.cuda()
+    state = TensorMultiModal(c(t["time"]), c(t.get("xt")), c(t["kt"]), c(t["mask"]))
+    batch = batch_of(g)
+    heads = model(state, batch)
+    lc, ld = model.loss_fn(heads, state, batch)
+    close(lc, t["loss_continuous"], rtol=1e-4, atol=1e-6)
+    close(ld, t["loss_discrete"], rtol=1e-4, atol=1e-6)
+    close(model.loss_multimode([lc, ld]), t["loss"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", MODEL_GOLDENS)
+def test_generation_injected(golden, name):
+    from tensorclass import TensorMultiModal
+    from datamodules.datasets import DataCoupling
+    g = golden(name)
+    t = g.t
+    tags = sorted({k.split(":")[0] for k in t if k.startswith("gen")})
+    for tag in tags:
+        steps = int(tag[3:])
+        model = build(g, num_timesteps=steps)
+        c = lambda a: None if a is None else a.cuda()
+        src = TensorMultiModal(None, c(t.get(tag + ":src_x")), c(t[tag + ":src_k"]), c(t[tag + ":src_mask"]))
+        batch = DataCoupling(src, TensorMultiModal(None, None, None, src.mask), None)
+        state = TensorMultiModal(torch.zeros_like(src.mask), None if src.continuous is None else src.continuous.clone(),
+                                 src.discrete.clone(), src.mask)
+        noise = {}
+        if tag + ":delta_n" in t:
+            noise["delta_n"] = t[tag + ":delta_n"].cuda()
+        if tag + ":u_jump" in t:
+            noise["u_jump"] = t[tag + ":u_jump"].cuda()
+        paths = model.simulate_dynamics(state, batch, noise=noise)
+        assert paths.discrete.shape[0] == 2 and paths.time.shape == (2,) + tuple(src.mask.shape)
+        assert torch.equal(paths.discrete[0].cpu(), t[tag + ":src_k"])
+        if tag + ":final_x" in t:
+            close(paths.continuous[1], t[tag + ":final_x"], rtol=1e-4, atol=2e-5)
+        agree = (paths.discrete[1].cpu() == t[tag + ":final_k"]).float().mean().item()
+        assert agree == 1.0, f"{name}/{tag}: final-k agreement {agree}"
+
+
+def test_predict_step_end_to_end(golden):
+    """Philox source + in-kernel noise: shapes, dtypes, ranges and determinism."""
+    from tensorclass import TensorMultiModal
+    from datamodules.datasets import DataCoupling
+    g = golden("mm_mid")
+    model = build(g, num_timesteps=20)
+    B, N = 64, 16
+    mask = torch.ones(B, N, 1, dtype=torch.int64, device="cuda")
+    tgt = TensorMultiModal(None, torch.zeros(B, N, 3, device="cuda"), torch.zeros(B, N, 1, dtype=torch.int64, device="cuda"), mask)
+    outs = []
+    for _ in range(2):
+        model.manual_seed(123)
+        paths, target = model.predict_step(DataCoupling(TensorMultiModal(), tgt, None), 0)
+        outs.append(paths)
+    p = outs[0]
+    assert p.continuous.shape == (2, B, N, 3) and p.discrete.shape == (2, B, N, 1) and p.discrete.dtype == torch.int64
+    assert not p.continuous.is_cuda
+    assert int(p.discrete.min()) >= 0 and int(p.discrete.max()) < 8
+    assert torch.isfinite(p.continuous).all()
+    assert torch.equal(outs[0].discrete, outs[1].discrete) and torch.equal(outs[0].continuous, outs[1].continuous)

@@ -460,7 +460,7 @@ def main():
     # the one data artefact we reuse from the reference: the AOJ multiplicity pmf
     with open(REF + "/tests/resources/metadata.json") as f:
         meta = json.load(f)
-    with open(os.path.join(OUT, "aoj_multiplicity_pmf.json"), "w") as f:
+    with open(os.path.join(OUT, "metadata.json"), "w") as f:
         json.dump({"source": "reference tests/resources/metadata.json 'categorical_probs'",
                    "max_num_particles_per_jet": meta["max_num_particles_per_jet"],
                    "categorical_probs": meta["categorical_probs"]}, f)

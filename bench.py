@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: generated jets/s @128 particles, 100 solver steps (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S3|S2] [--batch B]
+
+One "step" = one full pass of the generation hot path over one batch of synthetic
+AOJ-shaped clouds per rank: on-device SourceUniform draw (multiplicity masks from the AOJ
+pmf) followed by the 100-point Euler / tau-leap loop (2 encoder forwards + K-B + K-C per grid
+point for S3).  Everything is resident in HBM; outputs stay on the device.  Ranks shard the
+jets (weak scaling), no collective on the data path.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     -- the dominant kernel (the fp32-MFMA per-particle linear layer), timed live with
+                  HIP events on the launch stream during one extra profiled pass
+  cpu_baseline -- the CPU oracle (op-for-op eager PyTorch restatement of the reference) timed
+                  on the host cores over a bounded sample of the same workload (rank 0, N=1)
+  training     -- training jets/s of the same model (fwd+bwd+AdamW), when available
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "multimodal-bridges_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {"S3": "configs/S3_multimodal.yaml", "S2": "configs/S2_discrete.yaml"}
+
+
+def build_model(workload, steps_per_gen, device):
+    import yaml
+    from pipeline.configs import ExperimentConfigs
+    from model.multimodal_bridge_matching import MultiModalBridgeMatching
+    with open(os.path.join(ROOT, WORKLOADS[workload])) as fh:
+        cfg = yaml.safe_load(fh)
+    cfg["data"]["target_path"] = os.path.join(ROOT, "tests", "golden")
+    cfg["model"]["num_timesteps"] = steps_per_gen
+    config = ExperimentConfigs(cfg)
+    torch.manual_seed(0)
+    model = MultiModalBridgeMatching(config)
+    return model.to(device), config
+
+
+def gen_batch(config, B, device):
+    from tensorclass import TensorMultiModal
+    from datamodules.datasets import DataCoupling
+    N = config.data.max_num_particles
+    shape_only = TensorMultiModal(None, None, None, torch.ones(B, N, 1, dtype=torch.int64, device=device))
+    if config.data.modality != "discrete":
+        shape_only.continuous = torch.zeros(B, N, config.data.dim_continuous, device=device)
+    shape_only.discrete = torch.zeros(B, N, 1, dtype=torch.int64, device=device)
+    return DataCoupling(TensorMultiModal(), shape_only, None)
+
+
+def one_generation(model, config, B, device):
+    batch = gen_batch(config, B, device)
+    paths, _ = model.predict_step(batch, 0, to_cpu=False)
+    return paths
+
+
+def profile_dominant_kernel(model, config, B, device):
+    """One extra generation pass with every C-ABI call bracketed by HIP events."""
+    import mmb_hip
+    mmb_hip.PROFILE = []
+    one_generation(model, config, B, device)
+    torch.cuda.synchronize()
+    rec, mmb_hip.PROFILE = mmb_hip.PROFILE, None
+    groups = {}
+    for name, meta, e0, e1 in rec:
+        ms = e0.elapsed_time(e1)
+        key = name
+        if name == "mmb_linear_cat":
+            key = "mmb_linear_cat[per-particle]" if meta["M"] > 4096 else "mmb_linear_cat[per-jet]"
+        g = groups.setdefault(key, {"ms": 0.0, "n": 0, "flops": 0.0})
+        g["ms"] += ms
+        g["n"] += 1
+        if meta:
+            g["flops"] += meta["flops"]
+    return groups
+
+
+def cpu_baseline(model, config, workload, n_jets, n_steps):
+    """CPU oracle on a bounded sample: n_jets jets, the first n_steps of the 100-point grid."""
+    from oracle import model as OM, source as OS
+    from datamodules.synthetic import load_pmf
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    m = config.model
+    flat = {"time_eps": m.time_eps, "num_timesteps": m.num_timesteps, "gamma": m.gamma, "sigma": m.sigma,
+            "thermostat_fn": m.thermostat_fn, "solver_continuous": m.solver_continuous,
+            "solver_discrete": m.solver_discrete, "vocab_size": config.data.vocab_size,
+            "encoder_name": config.encoder.name, "skip_connection": config.encoder.skip_connection}
+    N = config.data.max_num_particles
+    pmf = load_pmf(os.path.join(ROOT, "tests", "golden"))
+    threads = torch.get_num_threads()
+    t0 = time.perf_counter()
+    src = OS.source_uniform((n_jets, N), config.data.modality, config.data.vocab_size, config.data.dim_continuous,
+                            pmf, sample_masks=True)
+    with torch.no_grad():
+        OM.simulate_dynamics(p, flat, src, noise=None, max_steps=n_steps)
+    dt = time.perf_counter() - t0
+    full = dt / n_steps * m.num_timesteps
+    return {"value": n_jets / full, "unit": "jets/s", "cores": threads, "kind": "port",
+            "sample": f"{n_jets} jets x first {n_steps} of {m.num_timesteps} grid points of {workload} "
+                      f"(source sampling included), {dt:.1f} s measured, scaled to the full grid"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="S3", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=1024, help="jets per rank per step")
+    ap.add_argument("--solver-steps", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-jets", type=int, default=128)
+    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--no-train", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    model, config = build_model(args.workload, args.solver_steps, device)
+    model.eval()
+    model.manual_seed(0xA0A0, rank)
+    B = args.batch
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_generation(model, config, B, device)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_generation(model, config, B, device)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    jets = B * world * args.steps
+    value = jets / elapsed
+
+    training = None
+    if not args.no_train:
+        try:
+            from pipeline.experiment import bench_training
+            training = bench_training(model, config, B, device, dist, steps=max(args.steps * 5, 10), warmup=3)
+        except Exception as exc:                                   # reported, never hidden
+            training = {"error": f"{type(exc).__name__}: {exc}"}
+
+    if rank == 0:
+        groups = profile_dominant_kernel(model, config, B, device)
+        dom = groups.get("mmb_linear_cat[per-particle]")
+        total_ms = sum(g["ms"] for g in groups.values())
+        roof = None
+        if dom:
+            achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            roof = {"kernel": "linear_cat_kernel (fp32 MFMA 32x32x2, per-particle layers)", "bound": "mfma",
+                    "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                    "launches": dom["n"], "avg_launch_us": dom["ms"] * 1e3 / dom["n"],
+                    "share_of_gpu_time": dom["ms"] / total_ms}
+        line = {
+            "metric": "generated jets/sec @128 particles, 100 steps", "value": value, "unit": "jets/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]} -- {config.encoder.name}, "
+                                   f"N={config.data.max_num_particles}, {args.solver_steps} grid points, "
+                                   f"{config.model.solver_continuous}+{config.model.solver_discrete}",
+                       "jets_per_rank_per_step": B, "parallelism": f"jets sharded over {world} rank(s), no collective"},
+            "roofline": roof,
+            "kernel_time_ms": {k: round(v["ms"], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])},
+        }
+        if training is not None:
+            line["training"] = training
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(model, config, args.workload, args.cpu_jets, args.cpu_steps)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

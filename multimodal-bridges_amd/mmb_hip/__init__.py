@@ -79,9 +79,23 @@ def lib():
     return _lib
 
 
+# Optional in-process kernel timing for bench.py: set PROFILE to a list and every C-ABI call
+# is bracketed by HIP events recorded on the stream it is enqueued on (torch's current one).
+PROFILE = None
+PROFILE_META = None
+
+
 def call(name, *args):
     h = lib()
-    rc = getattr(h, name)(*args)
+    if PROFILE is not None:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(h, name)(*args)
+        e1.record()
+        PROFILE.append((name, PROFILE_META, e0, e1))
+    else:
+        rc = getattr(h, name)(*args)
     if rc != 0:
         raise MMBError(f"{name} failed (rc={rc}): {h.mmb_last_error().decode()}")
     return rc

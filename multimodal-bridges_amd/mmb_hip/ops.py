@@ -4,6 +4,7 @@ import ctypes as C
 
 import torch
 
+import mmb_hip as _m
 from . import call, MMBError
 
 THERMOSTATS = {"ConstantThermostat": 0, "InverseThermostat": 1, "LinearThermostat": 2,
@@ -273,9 +274,13 @@ def linear_cat(segs, W, bias, rows_per_jet, maskf=None, act=None, residual=None,
     op, ol = p2(out)
     r2p, r2l = p2(res2)
     o2p, o2l = p2(out2)
+    if _m.PROFILE is not None:
+        K = sum(widths)
+        _m.PROFILE_META = {"M": M, "K": K, "Nout": Nout, "flops": 2.0 * M * K * Nout}
     call("mmb_linear_cat", M, rows_per_jet, n, ptrs, widths, kinds, lds, f32(maskf, "maskf"),
          W.data_ptr(), W.stride(0), f32(bias, "bias"), Nout, ACT[act], rp, rl, f32(row_scale, "row_scale"),
          op, ol, f32(pre), ACT[post], _fl(drop_p), seed, offset, r2p, r2l, o2p, o2l, stream())
+    _m.PROFILE_META = None
     res = (out, out2) if two else out
     if want_pre:
         res = (res + (pre,)) if two else (res, pre)

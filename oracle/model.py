@@ -82,7 +82,7 @@ def time_grid(cfg):
     return ts, dt
 
 
-def simulate_dynamics(p, cfg, source, noise):
+def simulate_dynamics(p, cfg, source, noise=None, max_steps=None):
     """multimodal_bridge_matching.py:227-259 (+ solvers.py) with injected per-step noise:
     noise['delta_n'][i] (B,N,V) for tauleap; noise['u_jump'][i] (B,N) for discrete euler;
     noise['delta_w'][i] (B,N,Dc) for euler_maruyama.
@@ -100,7 +100,10 @@ def simulate_dynamics(p, cfg, source, noise):
     name, skip = cfg["encoder_name"], cfg.get("skip_connection", True)
     rates = None
     margins = []
+    noise = noise or {}
     for i, tv in enumerate(ts):
+        if max_steps is not None and i >= max_steps:      # bounded CPU-baseline sample (bench.py)
+            break
         time = torch.full((Bn, 1), tv.item())
         if x is not None:
             hc, _ = E_.forward(p, time, x, k, mask, name, skip)
@@ -108,14 +111,17 @@ def simulate_dynamics(p, cfg, source, noise):
                 x = S_.euler_step(x, hc, dt)
             else:
                 sig = B_.schrodinger_diffusion(time.unsqueeze(1).repeat(1, mask.shape[1], 1), cfg["sigma"])
-                x = S_.euler_maruyama_step(x, hc, dt, sig, noise["delta_w"][i])
+                dw = noise["delta_w"][i] if "delta_w" in noise else torch.randn_like(x)   # solvers.py:31
+                x = S_.euler_maruyama_step(x, hc, dt, sig, dw)
         if k is not None:
             _, hd = E_.forward(p, time, x, k, mask, name, skip)
             rates = B_.telegraph_rate(time, k, hd, cfg["gamma"], V, cfg["thermostat_fn"])
             if cfg["solver_discrete"] == "tauleap":
-                k = S_.tauleap_step(k, rates, noise["delta_n"][i], V)
+                dn = noise["delta_n"][i] if "delta_n" in noise else torch.poisson(rates * dt)  # solvers.py:64
+                k = S_.tauleap_step(k, rates, dn, V)
             else:
-                k, m = S_.discrete_euler_step(k, rates, dt, noise["u_jump"][i])
+                u = noise["u_jump"][i] if "u_jump" in noise else torch.rand(k.shape[:2])
+                k, m = S_.discrete_euler_step(k, rates, dt, u)
                 margins.append(m)
     if k is not None:
         k = torch.max(rates, dim=2)[1].unsqueeze(-1)

@@ -222,7 +222,39 @@ int mmb_embed(int B, int N, int Dc, int V, int Et, int Ec, int Ed,
               const float* t, float t_scalar, const float* x, const int64_t* k, const float* maskf,
               const float* fourier_W, const float* time_W, const float* time_b,
               const float* cont_W, const float* cont_b, const float* table,
-              float* temb, float* cont, float* disc, void* stream);
+              float* temb, float* cont, float* disc, float* fourier_feat, void* stream);
+/* fourier_feat (B,Et) | NULL: the sin/cos features (kept for the time-Linear weight gradient). */
+
+/* ---------------------------------------------------------------- backward (training) -- */
+/* These have no single reference line: they are the hand-written reverse of the layers above
+ * (what torch.autograd derives for encoders/epic.py:145-208 and embedder.py:63-83).
+
+ * Epilogue/activation gradient of mmb_linear_cat.  Forward was a = act(z); y1 = a + res1;
+ * y2 = dropout(post(y1)) + res2.  Given gY1 and/or gY2:
+ *   g1 = gY1 + gY2 * keep/(1-p) * post'(y1) ;  dZ = g1 * act'(z)
+ * post' takes its sign from y1, or from y2 - res2 when y1 was not stored; act' needs `pre`
+ * (GELU) or y1 (leaky-relu).  All matrices are (M,Nout) with their own leading dimension. */
+int mmb_act_bwd(int64_t M, int Nout, const float* gY1, int64_t gY1_ld, const float* gY2, int64_t gY2_ld,
+                const float* y1, int64_t y1_ld, const float* y2, int64_t y2_ld,
+                const float* res2, int64_t res2_ld, const float* pre, int64_t pre_ld,
+                int act, int post, float drop_p, uint64_t seed, uint64_t offset,
+                float* dZ, int64_t dz_ld, void* stream);
+
+/* out[b,:] (+)= sum_n x[b,n,:] * (maskf ? maskf[b,n] : 1): gradient of a per-jet segment. */
+int mmb_jet_sum(int B, int N, int H, const float* x, int64_t x_ld, const float* maskf,
+                float* out, int64_t out_ld, int accumulate, void* stream);
+
+/* gradient of mmb_meansum_pool: dX[b,n,:] (+)= mask*(dP[b,:H]/count[b] + 0.01*dP[b,H:2H]) */
+int mmb_pool_bwd(int B, int N, int H, const float* dP, int64_t dp_ld, const float* maskf,
+                 const int32_t* counts, float* dX, int64_t dx_ld, int accumulate, void* stream);
+
+/* dW (Nout,K) += dZ^T @ cat_s[X_s] and db (Nout) += column sums of dZ, same segment
+ * description as mmb_linear_cat; accumulates with fp32 atomics (zero the buffers first). */
+int mmb_grad_weight(int M, int rows_per_jet, int n_seg,
+                    const void* const* seg_ptr_host, const int* seg_width_host,
+                    const int* seg_kind_host, const int* seg_ld_host, const float* maskf,
+                    const float* dZ, int64_t dz_ld, int Nout, float* dW, int64_t dw_ld, float* db,
+                    void* stream);
 
 #ifdef __cplusplus
 }

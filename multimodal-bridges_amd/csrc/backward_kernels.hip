@@ -1,0 +1,287 @@
+// Backward kernels of the layered EPiC path (training): activation/epilogue gradient,
+// per-jet column sums, weight gradient (fp32 MFMA, dZ^T @ cat(X) with the concatenation never
+// materialised), pooling gradient.  Reference: the autograd of encoders/epic.py layers.
+#include "common.h"
+#include <utility>
+
+namespace mmb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int I> struct ICb { static constexpr int v = I; };
+template <typename F, int... Is>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Is...>) { (f(ICb<Is>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
+
+struct Seg {
+  const float* ptr;
+  int width;
+  int kind;
+  int ld;
+  int k_begin;
+};
+struct Segs {
+  Seg s[4];
+  int n;
+};
+
+__device__ inline float act_grad(int act, float ref) {
+  // ref: pre-activation z for GELU; any value with the sign of z for leaky-relu
+  if (act == MMB_ACT_GELU) {
+    const float c = 0.70710678118654752440f;
+    const float cdf = 0.5f * (1.0f + erff(ref * c));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * ref * ref);
+    return cdf + ref * pdf;
+  }
+  if (act == MMB_ACT_LRELU) return ref > 0.0f ? 1.0f : 0.01f;
+  return 1.0f;
+}
+
+// forward: a = act(z); y1 = a + res1; y2 = dropout(post(y1)) + res2
+// backward: g1 = gY1 + gY2 * keep/(1-p) * post'(y1);  dZ = g1 * act'(z)
+struct ActBwd {
+  const float *gY1, *gY2, *y1, *y2, *res2, *pre;
+  int64_t gY1_ld, gY2_ld, y1_ld, y2_ld, res2_ld, pre_ld, dz_ld;
+  int act, post;
+  float drop_p;
+  uint64_t seed, offset;
+};
+
+__global__ void __launch_bounds__(256)
+act_bwd_kernel(int64_t M, int Nout, ActBwd a, float* __restrict__ dZ) {
+  const int64_t total = M * (int64_t)Nout;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = e / Nout;
+    const int col = (int)(e - row * Nout);
+    float g = a.gY1 ? a.gY1[row * a.gY1_ld + col] : 0.0f;
+    if (a.gY2) {
+      float g2 = a.gY2[row * a.gY2_ld + col];
+      if (a.drop_p > 0.0f) {
+        uint32_t r[4];
+        philox4(a.seed, a.offset, (uint64_t)e >> 2, 0xD0D0u, r);
+        g2 = (u01(r[e & 3]) < a.drop_p) ? 0.0f : g2 / (1.0f - a.drop_p);
+      }
+      float s;
+      if (a.y1) s = a.y1[row * a.y1_ld + col];
+      else s = a.y2[row * a.y2_ld + col] - (a.res2 ? a.res2[row * a.res2_ld + col] : 0.0f);
+      g += g2 * act_grad(a.post, s);
+    }
+    if (a.act != MMB_ACT_NONE) {
+      const float ref = a.pre ? a.pre[row * a.pre_ld + col] : a.y1[row * a.y1_ld + col];
+      g *= act_grad(a.act, ref);
+    }
+    dZ[row * a.dz_ld + col] = g;
+  }
+}
+
+// out[b, c] (+)= sum_n x[b,n,c] * (maskf ? maskf[b,n] : 1)
+__global__ void __launch_bounds__(256)
+jet_sum_kernel(int N, int H, const float* __restrict__ x, int64_t x_ld, const float* __restrict__ maskf,
+               float* __restrict__ out, int64_t out_ld, int accumulate) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.x;
+  const int col = threadIdx.x & 63;
+  const int rg = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < H; c0 += 64) {
+    const int c = c0 + col;
+    float s = 0.0f;
+    if (c < H)
+      for (int n = rg; n < N; n += 4) {
+        const int64_t p = (int64_t)b * N + n;
+        const float v = x[p * x_ld + c];
+        s += maskf ? v * maskf[p] : v;
+      }
+    red[rg][col] = s;
+    __syncthreads();
+    if (rg == 0 && c < H) {
+      const float tot = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+      float* o = out + (int64_t)b * out_ld + c;
+      *o = accumulate ? *o + tot : tot;
+    }
+    __syncthreads();
+  }
+}
+
+// dX[b,n,c] (+)= m[b,n] * ( dP[b,c]/cnt[b] + 0.01*dP[b,H+c] )      (epic.py:100-107 backward)
+__global__ void __launch_bounds__(256)
+pool_bwd_kernel(int64_t P, int N, int H, const float* __restrict__ dP, int64_t dp_ld,
+                const float* __restrict__ maskf, const int32_t* __restrict__ counts, float* __restrict__ dX,
+                int64_t dx_ld, int accumulate) {
+  const int64_t total = P * (int64_t)H;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = e / H;
+    const int c = (int)(e - p * H);
+    const int64_t b = p / N;
+    const float g = maskf[p] * (dP[b * dp_ld + c] / (float)counts[b] + 0.01f * dP[b * dp_ld + H + c]);
+    float* o = dX + p * dx_ld + c;
+    *o = accumulate ? *o + g : g;
+  }
+}
+
+// dW[o, k] += sum_m dZ[m, o] * cat(X)[m, k] ;  db[o] += sum_m dZ[m, o]  (bias = extra column k == K)
+// grid.x: row slabs, grid.y: 32-wide tiles of o.  Wave w of the block owns column tiles
+// jt = w + 4q (q < NJ).  Operands go straight from global memory to the MFMA fragments: for the
+// transposed product lane l reads dZ[row][o0 + (l&31)] / X[row][j0 + (l&31)] -- 128-byte
+// coalesced rows -- and lane half (l>>5) takes the odd/even row of the pair.
+template <int NJ>
+__global__ void __launch_bounds__(256)
+grad_weight_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restrict__ maskf,
+                   const float* __restrict__ dZ, int64_t dz_ld, int Nout, float* __restrict__ dW,
+                   int64_t dw_ld, float* __restrict__ db, int rows_per_block) {
+  constexpr int U = 8;                            // row pairs in flight per step
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int half = lane >> 5;
+  const int i32 = lane & 31;
+  const int o0 = blockIdx.y * 32;
+  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_end = min(M, r_begin + rows_per_block);
+  const bool o_ok = (o0 + i32) < Nout;
+
+  // resolve this lane's input column for each of its tiles once
+  const float* base[NJ];
+  int ld[NJ], kind[NJ];
+  sfor<NJ>([&](auto qc) {
+    constexpr int q = decltype(qc)::v;
+    const int col = (wave + 4 * q) * 32 + i32;
+    base[q] = nullptr; ld[q] = 0; kind[q] = -1;                 // -1: beyond K+1 -> zero
+    if (col == K) kind[q] = 3;                                   // bias column: constant one
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (s < sg.n && col >= sg.s[s].k_begin && col < sg.s[s].k_begin + sg.s[s].width) {
+        base[q] = sg.s[s].ptr + (col - sg.s[s].k_begin);
+        ld[q] = sg.s[s].ld;
+        kind[q] = sg.s[s].kind;
+      }
+  });
+
+  f32x16 acc[NJ];
+  sfor<NJ>([&](auto qc) {
+    constexpr int q = decltype(qc)::v;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[q][e] = 0.0f;
+  });
+
+  for (int m0 = r_begin; m0 < r_end; m0 += 2 * U) {
+    float a[U];
+    float b[U][NJ];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = m0 + 2 * u + half;
+      const bool ok = row < r_end;
+      const int rr = ok ? row : r_begin;
+      a[u] = (ok && o_ok) ? dZ[(int64_t)rr * dz_ld + o0 + i32] : 0.0f;
+      const int jet = rr / rows_per_jet;
+      sfor<NJ>([&](auto qc) {
+        constexpr int q = decltype(qc)::v;
+        float v = 0.0f;
+        if (ok) {
+          if (kind[q] == MMB_SEG_ROW) v = base[q][(int64_t)rr * ld[q]];
+          else if (kind[q] == MMB_SEG_JET) v = base[q][(int64_t)jet * ld[q]];
+          else if (kind[q] == MMB_SEG_JET_MASK) v = base[q][(int64_t)jet * ld[q]] * maskf[rr];
+          else if (kind[q] == 3) v = 1.0f;
+        }
+        b[u][q] = v;
+      });
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      sfor<NJ>([&](auto qc) {
+        constexpr int q = decltype(qc)::v;
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][q], acc[q], 0, 0, 0);
+      });
+  }
+
+  sfor<NJ>([&](auto qc) {
+    constexpr int q = decltype(qc)::v;
+    const int col = (wave + 4 * q) * 32 + i32;
+    sfor<16>([&](auto ec) {
+      constexpr int e = decltype(ec)::v;
+      const int o = o0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+      if (o < Nout) {
+        if (col < K) atomicAdd(&dW[(int64_t)o * dw_ld + col], acc[q][e]);
+        else if (col == K && db) atomicAdd(&db[o], acc[q][e]);
+      }
+    });
+  });
+}
+
+}  // namespace mmb
+
+using namespace mmb;
+
+extern "C" int mmb_act_bwd(int64_t M, int Nout, const float* gY1, int64_t gY1_ld, const float* gY2, int64_t gY2_ld,
+                           const float* y1, int64_t y1_ld, const float* y2, int64_t y2_ld, const float* res2,
+                           int64_t res2_ld, const float* pre, int64_t pre_ld, int act, int post, float drop_p,
+                           uint64_t seed, uint64_t offset, float* dZ, int64_t dz_ld, void* stream) {
+  MMB_REQUIRE(M > 0 && Nout > 0, "mmb_act_bwd: empty shape");
+  MMB_REQUIRE(dZ && (gY1 || gY2), "mmb_act_bwd: need dZ and at least one incoming gradient");
+  MMB_REQUIRE(act >= 0 && act <= 2 && post >= 0 && post <= 2, "mmb_act_bwd: bad activation");
+  if (gY2 && post != MMB_ACT_NONE) MMB_REQUIRE(y1 || y2, "mmb_act_bwd: post activation needs y1 or y2");
+  if (act == MMB_ACT_GELU) MMB_REQUIRE(pre, "mmb_act_bwd: GELU needs the pre-activation");
+  if (act == MMB_ACT_LRELU) MMB_REQUIRE(pre || y1, "mmb_act_bwd: leaky-relu needs pre or y1");
+  ActBwd a{gY1, gY2, y1, y2, res2, pre, gY1_ld, gY2_ld, y1_ld, y2_ld, res2_ld, pre_ld, dz_ld, act, post, drop_p, seed, offset};
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(stream_grid(M * Nout, 256)), dim3(256), 0, as_stream(stream), M, Nout, a, dZ);
+  return check_launch("mmb_act_bwd");
+}
+
+extern "C" int mmb_jet_sum(int B, int N, int H, const float* x, int64_t x_ld, const float* maskf, float* out,
+                           int64_t out_ld, int accumulate, void* stream) {
+  MMB_REQUIRE(B > 0 && N > 0 && H > 0, "mmb_jet_sum: empty shape");
+  MMB_REQUIRE(x && out && x_ld >= H && out_ld >= H, "mmb_jet_sum: bad argument");
+  hipLaunchKernelGGL(jet_sum_kernel, dim3(B), dim3(256), 0, as_stream(stream), N, H, x, x_ld, maskf, out, out_ld,
+                     accumulate);
+  return check_launch("mmb_jet_sum");
+}
+
+extern "C" int mmb_pool_bwd(int B, int N, int H, const float* dP, int64_t dp_ld, const float* maskf,
+                            const int32_t* counts, float* dX, int64_t dx_ld, int accumulate, void* stream) {
+  MMB_REQUIRE(B > 0 && N > 0 && H > 0, "mmb_pool_bwd: empty shape");
+  MMB_REQUIRE(dP && maskf && counts && dX && dp_ld >= 2 * H && dx_ld >= H, "mmb_pool_bwd: bad argument");
+  const int64_t P = (int64_t)B * N;
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(stream_grid(P * H, 256)), dim3(256), 0, as_stream(stream), P, N, H, dP,
+                     dp_ld, maskf, counts, dX, dx_ld, accumulate);
+  return check_launch("mmb_pool_bwd");
+}
+
+extern "C" int mmb_grad_weight(int M, int rows_per_jet, int n_seg, const void* const* seg_ptr, const int* seg_width,
+                               const int* seg_kind, const int* seg_ld, const float* maskf, const float* dZ,
+                               int64_t dz_ld, int Nout, float* dW, int64_t dw_ld, float* db, void* stream) {
+  MMB_REQUIRE(M > 0 && Nout > 0 && rows_per_jet > 0, "mmb_grad_weight: bad shape");
+  MMB_REQUIRE(n_seg >= 1 && n_seg <= 4 && seg_ptr && seg_width && seg_kind && seg_ld, "mmb_grad_weight: bad segments");
+  MMB_REQUIRE(dZ && dW && dz_ld >= Nout, "mmb_grad_weight: bad argument");
+  Segs sg;
+  sg.n = n_seg;
+  int K = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (i < n_seg) {
+      MMB_REQUIRE(seg_ptr[i] && seg_width[i] > 0 && seg_kind[i] >= 0 && seg_kind[i] <= 2 && seg_ld[i] >= seg_width[i],
+                  "mmb_grad_weight: segment %d invalid", i);
+      if (seg_kind[i] == MMB_SEG_JET_MASK) MMB_REQUIRE(maskf, "mmb_grad_weight: JET_MASK segment needs maskf");
+      sg.s[i] = Seg{(const float*)seg_ptr[i], seg_width[i], seg_kind[i], seg_ld[i], K};
+      K += seg_width[i];
+    } else {
+      sg.s[i] = Seg{nullptr, 0, 0, 0, 0};
+    }
+  }
+  MMB_REQUIRE(dw_ld >= K, "mmb_grad_weight: dw_ld < K");
+  const int TJ = (K + 1 + 31) / 32;              // +1: the bias column
+  const int NJ = (TJ + 3) / 4;
+  MMB_REQUIRE(NJ <= 5, "mmb_grad_weight: K=%d too wide (max 639)", K);
+  int rpb = 1024;
+  if (M < 64 * 1024) rpb = 256;
+  if (M < 4096) rpb = 64;
+  dim3 grid((M + rpb - 1) / rpb, (Nout + 31) / 32);
+  hipStream_t st = as_stream(stream);
+#define GW(NJ_) hipLaunchKernelGGL((grad_weight_kernel<NJ_>), grid, dim3(256), 0, st, M, rows_per_jet, sg, K, maskf, dZ, dz_ld, Nout, dW, dw_ld, db, rpb)
+  switch (NJ) {
+    case 1: GW(1); break;
+    case 2: GW(2); break;
+    case 3: GW(3); break;
+    case 4: GW(4); break;
+    default: GW(5); break;
+  }
+#undef GW
+  return check_launch("mmb_grad_weight");
+}

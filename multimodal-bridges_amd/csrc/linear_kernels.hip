@@ -10,8 +10,17 @@
 // Inside a K chunk the MFMA k index is permuted (k = half*BK/2 + step) so that every lane
 // reads BK/2 CONTIGUOUS floats for its fragment (dwordx4 global loads, ds_read_b128).
 #include "common.h"
+#include <utility>
 
 namespace mmb {
+
+// compile-time loop: guarantees constant indices into the accumulator vectors (a '#pragma
+// unroll' that the optimizer declines leaves them runtime-indexed, i.e. in scratch memory)
+template <int I> struct IC { static constexpr int v = I; };
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(IC<Is>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -104,7 +113,8 @@ linear_cat_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restri
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
 
   const int nchunks = (K + BK - 1) / BK;
-  float a_next[HALF];
+  float a_next[HALF];        // RAW prefetched values; the mask scale is applied when they are consumed
+  float a_scale_next = 1.0f;  // (multiplying at load time would force a vmcnt(0) right behind the load)
   float4 w_next[W_PER_T];
 
   auto load_a = [&](int chunk) {
@@ -126,16 +136,19 @@ linear_cat_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restri
 #pragma unroll
         for (int q = 0; q < HALF / 4; ++q) {
           float4 v = reinterpret_cast<const float4*>(src)[q];
-          a_next[4 * q + 0] = v.x * scale; a_next[4 * q + 1] = v.y * scale;
-          a_next[4 * q + 2] = v.z * scale; a_next[4 * q + 3] = v.w * scale;
+          a_next[4 * q + 0] = v.x; a_next[4 * q + 1] = v.y;
+          a_next[4 * q + 2] = v.z; a_next[4 * q + 3] = v.w;
         }
+        a_scale_next = scale;
       } else {
+        a_scale_next = 1.0f;
 #pragma unroll
         for (int q = 0; q < HALF; ++q) a_next[q] = 0.0f;
       }
     } else {
 #pragma unroll
       for (int q = 0; q < HALF; ++q) a_next[q] = fetch_cat(sg, ld_row, jet, m, kh + q);
+      a_scale_next = 1.0f;
     }
   };
 
@@ -184,7 +197,7 @@ linear_cat_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restri
     __syncthreads();                              // Ws[c&1] complete; Ws[(c+1)&1] free
     float a_cur[HALF];
 #pragma unroll
-    for (int q = 0; q < HALF; ++q) a_cur[q] = a_next[q];
+    for (int q = 0; q < HALF; ++q) a_cur[q] = a_next[q] * a_scale_next;
     if (c + 1 < nchunks) {
       load_a(c + 1);
       load_w(c + 1);
@@ -209,29 +222,30 @@ linear_cat_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restri
   }
 
   // epilogue.  C/D layout of 32x32x2: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
+  static_for<NT>([&](auto jc) {
+    constexpr int j = decltype(jc)::v;
     const int col = col0 + j * 32 + r32;
-    if (col >= Nout) continue;
-    const float bv = bias ? bias[col] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    const bool col_ok = col < Nout;
+    const float bv = (bias && col_ok) ? bias[col] : 0.0f;
+    static_for<16>([&](auto ic) {
+      constexpr int i = decltype(ic)::v;
       const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * half;
-      if (row >= M) continue;
-      float z = acc[j][i] + bv;
-      if (pre_act) pre_act[(int64_t)row * Nout + col] = z;
-      float y = apply_act(act, z);
-      if (residual) y += residual[(int64_t)row * res_ld + col];
-      if (row_scale) y *= row_scale[row];
-      if (Y) Y[(int64_t)row * y_ld + col] = y;
-      if (post.Y2) {
-        float y2 = apply_act(post.act, y);
-        if (post.drop_p > 0.0f) y2 = dropout_apply(y2, post.drop_p, post.seed, post.offset, (uint64_t)row * Nout + col);
-        if (post.res2) y2 += post.res2[(int64_t)row * post.res2_ld + col];
-        post.Y2[(int64_t)row * post.y2_ld + col] = y2;
+      if (col_ok && row < M) {
+        float z = acc[j][i] + bv;
+        if (pre_act) pre_act[(int64_t)row * Nout + col] = z;
+        float y = apply_act(act, z);
+        if (residual) y += residual[(int64_t)row * res_ld + col];
+        if (row_scale) y *= row_scale[row];
+        if (Y) Y[(int64_t)row * y_ld + col] = y;
+        if (post.Y2) {
+          float y2 = apply_act(post.act, y);
+          if (post.drop_p > 0.0f) y2 = dropout_apply(y2, post.drop_p, post.seed, post.offset, (uint64_t)row * Nout + col);
+          if (post.res2) y2 += post.res2[(int64_t)row * post.res2_ld + col];
+          post.Y2[(int64_t)row * post.y2_ld + col] = y2;
+        }
       }
-    }
-  }
+    });
+  });
 }
 
 // ---------------------------------------------------------------- weight norm ----------
@@ -299,7 +313,8 @@ meansum_pool_kernel(int N, int H, const float* __restrict__ x, int64_t x_ld, con
 // ---------------------------------------------------------------- embedder -------------
 __global__ void __launch_bounds__(64)
 time_embed_kernel(int Et, const float* __restrict__ t, float t_scalar, const float* __restrict__ fW,
-                  const float* __restrict__ lw, const float* __restrict__ lb, float* __restrict__ temb) {
+                  const float* __restrict__ lw, const float* __restrict__ lb, float* __restrict__ temb,
+                  float* __restrict__ feat_out) {
   extern __shared__ float feat[];                  // Et fourier features
   const int b = blockIdx.x;
   const float tt = t ? t[b] : t_scalar;
@@ -312,6 +327,8 @@ time_embed_kernel(int Et, const float* __restrict__ t, float t_scalar, const flo
     feat[hE + i] = cosf(a);
   }
   __syncthreads();
+  if (feat_out)
+    for (int i = threadIdx.x; i < 2 * hE; i += 64) feat_out[(int64_t)b * Et + i] = feat[i];
   for (int o = threadIdx.x; o < Et; o += 64) {
     float s = 0.0f;
     for (int k = 0; k < 2 * hE; ++k) s += feat[k] * lw[o * Et + k];
@@ -453,7 +470,8 @@ extern "C" int mmb_meansum_pool(int B, int N, int H, const float* x, int64_t x_l
 extern "C" int mmb_embed(int B, int N, int Dc, int V, int Et, int Ec, int Ed, const float* t, float t_scalar,
                          const float* x, const int64_t* k, const float* maskf, const float* fourier_W,
                          const float* time_W, const float* time_b, const float* cont_W, const float* cont_b,
-                         const float* table, float* temb, float* cont, float* disc, void* stream) {
+                         const float* table, float* temb, float* cont, float* disc, float* fourier_feat,
+                         void* stream) {
   MMB_REQUIRE(B > 0 && N > 0, "mmb_embed: empty shape");
   MMB_REQUIRE(Et > 0 && Et % 2 == 0, "mmb_embed: dim_emb_time=%d must be even and > 0", Et);
   MMB_REQUIRE(fourier_W && time_W && time_b && temb && maskf, "mmb_embed: NULL argument");
@@ -462,7 +480,7 @@ extern "C" int mmb_embed(int B, int N, int Dc, int V, int Et, int Ec, int Ed, co
   if (has_d) MMB_REQUIRE(k && table && Ed > 0 && V > 0, "mmb_embed: discrete mode needs k,table");
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(time_embed_kernel, dim3(B), dim3(64), Et * sizeof(float), st, Et, t, t_scalar, fourier_W,
-                     time_W, time_b, temb);
+                     time_W, time_b, temb, fourier_feat);
   int rc = check_launch("mmb_embed(time)");
   if (rc) return rc;
   if (has_c || has_d) {

@@ -1,3 +1,208 @@
-"""placeholder -- replaced below"""
+"""Reverse pass of the taped HIP forward (training).
+
+The forward (encoders/epic.py, embedder.py) records one entry per launched op.  This module
+replays the tape backwards with the hand-written gradient kernels of libmmb_hip.so:
+
+  linear : mmb_act_bwd (epilogue/activation) -> mmb_grad_weight (dW, db; fp32 MFMA) ->
+           mmb_weight_norm_bwd (dv, dg) -> per segment mmb_linear_cat with W^T (dX) or
+           mmb_jet_sum + a per-jet mmb_linear_cat (gradient of the broadcast segments)
+  pool   : mmb_pool_bwd
+  embed  : mmb_grad_weight on the Fourier features / the raw kinematics
+
+Gradients of activations live in a GradStore keyed by the activation's storage, so a column
+slice of a buffer (the zero-copy concat of the two branch outputs) automatically gets the
+matching slice of the buffer's gradient.  Parameters that take no part in the forward (the
+truncated embedding, quirk Q1; the never-executed last fused layer, K2) keep grad None, as
+in the reference.
+"""
+import torch
+
+from mmb_hip import ops
+from mmb_hip.ops import SEG_ROW, SEG_JET, SEG_JET_MASK
+
+
+class GradStore:
+    def __init__(self):
+        self.bufs = {}
+
+    @staticmethod
+    def _key(t):
+        return t.untyped_storage().data_ptr()
+
+    def seed(self, t, g):
+        """Gradient of a tensor that owns its whole storage."""
+        self.bufs[self._key(t)] = (g.contiguous().reshape(-1), t)
+
+    def view(self, t):
+        key = self._key(t)
+        if key not in self.bufs:
+            n = t.untyped_storage().nbytes() // 4
+            self.bufs[key] = (torch.zeros(n, dtype=torch.float32, device=t.device), t)
+        return self.bufs[key][0].as_strided(t.shape, t.stride(), t.storage_offset())
+
+    def get(self, t):
+        if t is None:
+            return None
+        key = self._key(t)
+        if key not in self.bufs:
+            return None
+        return self.bufs[key][0].as_strided(t.shape, t.stride(), t.storage_offset())
+
+
+def _acc_param(p, g):
+    g = g.reshape(p.shape)
+    if p.grad is None:
+        p.grad = g.clone() if g.untyped_storage().data_ptr() == p.untyped_storage().data_ptr() else g
+    else:
+        p.grad.add_(g)
+
+
+def _produced(tape):
+    keys = set()
+    k = GradStore._key
+    for e in tape:
+        if e[0] == "linear":
+            for t in (e[9], e[10]):
+                if t is not None:
+                    keys.add(k(t))
+        elif e[0] == "pool":
+            keys.add(k(e[2]))
+        elif e[0] == "cat":
+            keys.add(k(e[2]))
+        elif e[0] == "embed":
+            keys.add(k(e[4]))
+            if e[5] is not None:
+                keys.add(k(e[5]))
+    return keys
+
+
+def _linear_bwd(e, store, produced, mi, seed):
+    _, layer, N, segs, act, res1, post, res2, pre, y1, y2, p, off = e
+    gY1, gY2 = store.get(y1), store.get(y2)
+    if gY1 is None and gY2 is None:
+        return
+    ref = y1 if y1 is not None else y2
+    M, Nout = ref.shape
+    dZ = ops.act_bwd(M, Nout, gY1, gY2, y1, y2, res2, pre, act, post, p, seed, off)
+    if res2 is not None and gY2 is not None and GradStore._key(res2) in produced:
+        store.view(res2).add_(gY2)
+    if res1 is not None and GradStore._key(res1) in produced:
+        store.view(res1).add_(dZ)
+    # ---- parameters
+    W, inv = layer.weight(want_inv=True)
+    dW = torch.zeros_like(W)
+    db = torch.zeros(Nout, dtype=torch.float32, device=W.device)
+    maskf = mi.maskf
+    ops.grad_weight(segs, N, maskf, dZ, dW, db)
+    roff, rlen = layer._row_tables(W.device)
+    dv, dg = ops.weight_norm_bwd(roff, rlen, layer.weight_v.detach().reshape(-1), layer.weight_g.detach().reshape(-1),
+                                 inv, dW.reshape(-1))
+    _acc_param(layer.weight_v, dv)
+    _acc_param(layer.weight_g, dg)
+    _acc_param(layer.bias, db)
+    # ---- inputs
+    need = [GradStore._key(t) in produced for t, _ in segs]
+    if not any(need):
+        return
+    WT = W.t().contiguous()
+    B = mi.B
+    S = Sm = None
+    koff = 0
+    for (t, kind), nd in zip(segs, need):
+        Ks = t.shape[1]
+        if nd:
+            gx = store.view(t)
+            Wseg = WT[koff:koff + Ks]
+            if kind == SEG_ROW:
+                ops.linear_cat([(dZ, SEG_ROW)], Wseg, None, N, residual=gx, out=gx)
+            else:
+                if kind == SEG_JET:
+                    if S is None:
+                        S = ops.jet_sum(dZ, B, N)
+                    red = S
+                else:
+                    if Sm is None:
+                        Sm = ops.jet_sum(dZ, B, N, maskf=maskf)
+                    red = Sm
+                ops.linear_cat([(red, SEG_ROW)], Wseg, None, 1, residual=gx, out=gx)
+        koff += Ks
+
+
+def _embed_bwd(e, store, mi):
+    _, emb, x, mi_, temb, cont, feat = e
+    g_t = store.get(temb)
+    lin = emb.time_embedding[1]
+    if g_t is not None:
+        dW = torch.zeros_like(lin.weight)
+        db = torch.zeros_like(lin.bias)
+        ops.grad_weight([(feat, SEG_ROW)], 1, None, g_t.contiguous(), dW, db)
+        _acc_param(lin.weight, dW)
+        _acc_param(lin.bias, db)
+    g_c = store.get(cont) if cont is not None else None
+    if g_c is not None:
+        ce = emb.continuous_embedding
+        d_pre = g_c * mi_.maskf.reshape(-1, 1)
+        dW = torch.zeros_like(ce.weight)
+        db = torch.zeros_like(ce.bias)
+        ops.grad_weight([(x.reshape(-1, x.shape[-1]), SEG_ROW)], mi_.N, None, d_pre, dW, db)
+        _acc_param(ce.weight, dW)
+        _acc_param(ce.bias, db)
+
+
+def run_backward(model, tape, heads, d_hc, d_hd, d_s=None, scale=None):
+    """Fill .grad of every parameter that took part in the taped forward."""
+    store = GradStore()
+    if scale is not None:
+        d_hc = None if d_hc is None else d_hc * scale
+        d_hd = None if d_hd is None else d_hd * scale
+        d_s = None if d_s is None else d_s * scale
+    if d_hc is not None:
+        store.seed(heads.continuous, d_hc.reshape(-1, d_hc.shape[-1]))
+    if d_hd is not None:
+        store.seed(heads.discrete, d_hd.reshape(-1, d_hd.shape[-1]))
+    produced = _produced(tape)
+    mi = next(e[3] for e in tape if e[0] == "embed")
+    seed = model.seed
+    for e in reversed(tape):
+        kind = e[0]
+        if kind == "linear":
+            _linear_bwd(e, store, produced, mi, seed)
+        elif kind == "pool":
+            gP = store.get(e[2])
+            if gP is not None and GradStore._key(e[1]) in produced:
+                ops.pool_bwd(gP, mi, store.view(e[1]), True)
+        elif kind == "cat":
+            g = store.get(e[2])
+            if g is not None:
+                o = 0
+                for part in e[1]:
+                    w = part.shape[1]
+                    if GradStore._key(part) in produced:
+                        store.view(part).add_(g[:, o:o + w])
+                    o += w
+        elif kind == "embed":
+            _embed_bwd(e, store, mi)
+    lw = getattr(model.loss_multimode, "loss_weights", None)
+    if d_s is not None and isinstance(lw, torch.nn.Parameter):
+        _acc_param(lw, d_s)
+
+
+class _TapeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, loss_val, holder):
+        ctx.holder = holder
+        return loss_val.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        h = ctx.holder
+        ctx.holder = None
+        run_backward(h["model"], h["tape"], h["heads"], h["d_hc"], h["d_hd"], h["d_s"], scale=g)
+        return None, None, None
+
+
 def attach_backward(model, loss, tape, heads, d_hc, d_hd, d_s):
-    return loss[0]
+    """Return the scalar loss wired into autograd so that `loss.backward()` replays the tape."""
+    anchor = torch.zeros(1, device=loss.device, requires_grad=True)
+    holder = {"model": model, "tape": tape, "heads": heads, "d_hc": d_hc, "d_hd": d_hd, "d_s": d_s}
+    return _TapeFn.apply(anchor, loss[0].detach(), holder)

@@ -130,13 +130,14 @@ class MultiModalEmbedder(nn.Module):
         has_d = discrete is not None and hasattr(self, "discrete_embedding")
         x = continuous.contiguous() if has_c else None
         k = discrete.contiguous() if has_d else None
-        temb, cont, disc = ops.embed(
+        r = ops.embed(
             t, ts, x, k, mi, te[0].W.detach(), te[1].weight.detach(), te[1].bias.detach(),
             self.continuous_embedding.weight.detach() if has_c else None,
             self.continuous_embedding.bias.detach() if has_c else None,
-            self.discrete_embedding.table() if has_d else None)
+            self.discrete_embedding.table() if has_d else None, want_feat=tape is not None)
+        temb, cont, disc = r[0], r[1], r[2]
         if tape is not None:
-            tape.append(("embed", self, t, ts, x, mi, temb, cont))
+            tape.append(("embed", self, x, mi, temb, cont, r[3]))
         return LocalState(temb, cont, disc, mask, mi)
 
     def forward(self, state: TensorMultiModal, batch=None):

@@ -50,7 +50,14 @@ SIGNATURES = {
                        C.c_int64, c_f32p, C.c_int64, c_stream],
     "mmb_meansum_pool": [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, c_i32p, c_f32p, C.c_int64, c_stream],
     "mmb_embed": [C.c_int] * 7 + [c_f32p, C.c_float, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
-                                  c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
+                                  c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
+    "mmb_act_bwd": [C.c_int64, C.c_int] + [c_f32p, C.c_int64] * 6 + [C.c_int, C.c_int, C.c_float, C.c_uint64,
+                                                                      C.c_uint64, c_f32p, C.c_int64, c_stream],
+    "mmb_jet_sum": [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int, c_stream],
+    "mmb_pool_bwd": [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, c_i32p, c_f32p, C.c_int64, C.c_int,
+                     c_stream],
+    "mmb_grad_weight": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                        C.POINTER(C.c_int), c_f32p, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p, c_stream],
 }
 
 _lib = None

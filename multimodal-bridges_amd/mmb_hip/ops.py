@@ -298,7 +298,7 @@ def meansum_pool(x, mi, out=None):
     return out
 
 
-def embed(t, t_scalar, x, k, mi, fourier_W, time_W, time_b, cont_W, cont_b, table):
+def embed(t, t_scalar, x, k, mi, fourier_W, time_W, time_b, cont_W, cont_b, table, want_feat=False):
     B, N = mi.B, mi.N
     dev = mi.maskf.device
     Et = time_W.shape[0]
@@ -308,8 +308,61 @@ def embed(t, t_scalar, x, k, mi, fourier_W, time_W, time_b, cont_W, cont_b, tabl
     temb = torch.empty(B, Et, dtype=torch.float32, device=dev)
     cont = torch.empty(B * N, Ec, dtype=torch.float32, device=dev) if x is not None else None
     disc = torch.empty(B * N, Ed, dtype=torch.float32, device=dev) if k is not None else None
+    feat = torch.empty(B, Et, dtype=torch.float32, device=dev) if want_feat else None
     call("mmb_embed", B, N, Dc, V, Et, Ec, Ed, f32(t, "t"), _fl(t_scalar), f32(x, "x"), i64(k, "k"), f32(mi.maskf),
          f32(fourier_W), f32(time_W), f32(time_b), f32(cont_W if x is not None else None),
          f32(cont_b if x is not None else None), f32(table if k is not None else None), f32(temb), f32(cont),
-         f32(disc), stream())
-    return temb, cont, disc
+         f32(disc), f32(feat), stream())
+    return (temb, cont, disc, feat) if want_feat else (temb, cont, disc)
+
+
+# ------------------------------------------------------------------------ backward
+def _pl(t):
+    return (t.data_ptr(), t.stride(0)) if t is not None else (None, 0)
+
+
+def _seg_arrays(segs):
+    n = len(segs)
+    ptrs = (C.c_void_p * n)()
+    widths = (C.c_int * n)()
+    kinds = (C.c_int * n)()
+    lds = (C.c_int * n)()
+    M = None
+    for i, (t, kind) in enumerate(segs):
+        ptrs[i], widths[i], kinds[i], lds[i] = t.data_ptr(), t.shape[1], kind, t.stride(0)
+        if kind == SEG_ROW:
+            M = t.shape[0]
+    return n, ptrs, widths, kinds, lds, M
+
+
+def act_bwd(M, Nout, gY1, gY2, y1, y2, res2, pre, act, post, drop_p=0.0, seed=0, offset=0):
+    ref = gY1 if gY1 is not None else gY2
+    dZ = torch.empty(M, Nout, dtype=torch.float32, device=ref.device)
+    call("mmb_act_bwd", M, Nout, *_pl(gY1), *_pl(gY2), *_pl(y1), *_pl(y2), *_pl(res2), *_pl(pre), ACT[act], ACT[post],
+         _fl(drop_p), seed, offset, dZ.data_ptr(), dZ.stride(0), stream())
+    return dZ
+
+
+def jet_sum(x, B, N, maskf=None, out=None, accumulate=False):
+    H = x.shape[1]
+    if out is None:
+        out = torch.empty(B, H, dtype=torch.float32, device=x.device)
+        accumulate = False
+    call("mmb_jet_sum", B, N, H, x.data_ptr(), x.stride(0), f32(maskf), out.data_ptr(), out.stride(0),
+         int(accumulate), stream())
+    return out
+
+
+def pool_bwd(dP, mi, dX, accumulate):
+    H = dX.shape[1]
+    call("mmb_pool_bwd", mi.B, mi.N, H, dP.data_ptr(), dP.stride(0), f32(mi.maskf), i32(mi.counts), dX.data_ptr(),
+         dX.stride(0), int(accumulate), stream())
+    return dX
+
+
+def grad_weight(segs, rows_per_jet, maskf, dZ, dW, db):
+    """dW (Nout,K) += dZ^T @ cat(segs); db (Nout) += colsum(dZ).  Buffers must be pre-zeroed."""
+    n, ptrs, widths, kinds, lds, M = _seg_arrays(segs)
+    Nout = dZ.shape[1]
+    call("mmb_grad_weight", M, rows_per_jet, n, ptrs, widths, kinds, lds, f32(maskf), dZ.data_ptr(), dZ.stride(0),
+         Nout, dW.data_ptr(), dW.stride(0), db.data_ptr() if db is not None else None, stream())

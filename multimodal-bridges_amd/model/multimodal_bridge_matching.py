@@ -209,8 +209,12 @@ class MultiModalBridgeMatching(nn.Module):
         losses, _, _ = self._loss_kernel(heads, state, batch, want_grad=False)
         return losses[0], losses[1]
 
-    def _step(self, batch, prefix, train):
-        state = self.sample_bridges(batch)
+    def _step(self, batch, prefix, train, noise=None):
+        state = self.sample_bridges(batch, noise=noise)
+        return self.step_from_state(state, batch, prefix, train)
+
+    def step_from_state(self, state, batch, prefix="train", train=True):
+        """Encoder forward (taped when training) + fused loss/gradient kernel on a given bridge state."""
         self._tape = [] if train else None
         try:
             heads = self.forward(state, batch)
@@ -228,8 +232,8 @@ class MultiModalBridgeMatching(nn.Module):
             out["loss"] = attach_backward(self, loss, tape, heads, d_hc, d_hd, d_s)
         return out
 
-    def training_step(self, batch: DataCoupling, batch_idx=0) -> Dict[str, torch.Tensor]:
-        return self._step(batch, "train", True)
+    def training_step(self, batch: DataCoupling, batch_idx=0, noise=None) -> Dict[str, torch.Tensor]:
+        return self._step(batch, "train", True, noise)
 
     def validation_step(self, batch: DataCoupling, batch_idx=0) -> Dict[str, torch.Tensor]:
         with torch.no_grad():

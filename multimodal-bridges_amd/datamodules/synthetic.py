@@ -43,3 +43,45 @@ def synthetic_target(B, N, metadata_dir, seed=1234, Dc=3, V=8, modality="multi-m
 def synthetic_batch(B, N, metadata_dir, **kw) -> DataCoupling:
     """DataCoupling with an absent source (the model samples it) and a synthetic target."""
     return DataCoupling(TensorMultiModal(), synthetic_target(B, N, metadata_dir, **kw), None)
+
+
+class SyntheticJetDataModule:
+    """Stand-in for the reference's JetDataModule(config) on synthetic AOJ-shaped jets
+    (config.data.num_jets, batch_size, split_ratios, max_num_particles).  The whole (small)
+    dataset lives in HBM; each rank iterates its own contiguous shard of the jets."""
+
+    def __init__(self, config):
+        self.config = config
+        self._train = self._val = self._test = None
+
+    def setup(self, stage=None, rank=0, world=1, device="cuda"):
+        d = self.config.data
+        n = int(d.num_jets or 1024)
+        full = synthetic_target(n, d.max_num_particles, d.target_path, seed=1234, Dc=max(d.dim_continuous, 1),
+                                V=d.vocab_size, modality=d.modality, device=device)
+        ratios = d.split_ratios or [0.8, 0.2]
+        n_train = int(ratios[0] * n)
+        base, rem = divmod(n_train, world)
+        lo = rank * base + min(rank, rem)
+        hi = lo + base + (1 if rank < rem else 0)
+        self._train = full[lo:hi]
+        nv = n - n_train
+        base, rem = divmod(nv, world)
+        lo = n_train + rank * base + min(rank, rem)
+        hi = lo + base + (1 if rank < rem else 0)
+        self._val = full[lo:hi]
+        self._test = self._val
+
+    def _batches(self, data):
+        bs = int(self.config.data.batch_size)
+        for i in range(0, len(data), bs):
+            yield DataCoupling(TensorMultiModal(), data[i:i + bs], None)
+
+    def train_dataloader(self):
+        return self._batches(self._train)
+
+    def val_dataloader(self):
+        return self._batches(self._val)
+
+    def predict_dataloader(self):
+        return self._batches(self._test)

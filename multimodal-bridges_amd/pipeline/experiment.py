@@ -1,0 +1,250 @@
+"""ExperimentPipeline: train() / generate() without Lightning (reference:
+pipeline/experiment.py:18-224).  One process per GPU (launch with torchrun); data-parallel
+training exchanges ONE flat fp32 gradient bucket per step through RCCL
+(torch.distributed backend "nccl" on ROCm); generation shards jets across ranks and gathers
+once at the end.
+
+    pipeline = ExperimentPipeline(datamodule_cls, config="configs/S3_multimodal.yaml")
+    pipeline.train(); pipeline.generate()
+
+The gradient payload is tiny (2.4 MB for S3) so the all-reduce is latency-bound: every
+parameter's .grad is a VIEW into one pre-allocated flat buffer (parameters without a gradient
+-- the truncated embedding Q1, the dead fused layer K2 -- stay zero there, which is what the
+reference's find_unused_parameters papers over), so a step costs exactly one collective, and
+the global-norm clip runs on the already averaged buffer.
+"""
+import json
+import os
+import time
+from typing import Optional
+
+import torch
+
+from pipeline.configs import ExperimentConfigs
+from tensorclass import TensorMultiModal
+from datamodules.datasets import DataCoupling
+
+
+class FlatGrads:
+    """All gradients as views of one flat fp32 buffer (single-bucket all-reduce)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+        off = 0
+        for p in self.params:                      # re-attach views if something replaced .grad
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def all_reduce_mean(self, dist, world):
+        if dist is not None and world > 1:
+            dist.all_reduce(self.flat)
+            self.flat.div_(world)
+
+    def clip_(self, max_norm):
+        """Global L2-norm clip (Lightning gradient_clip_val semantics), no host sync."""
+        if not max_norm:
+            return None
+        norm = torch.linalg.vector_norm(self.flat)
+        self.flat.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
+        return norm
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous shard [lo, hi) of rank; shards differ by at most one item."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _dist_env():
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    return world, rank, local
+
+
+class ExperimentPipeline:
+    def __init__(self, datamodule_cls=None, config=None, experiment_path: Optional[str] = None,
+                 load_ckpt: str = "last", accelerator: str = "gpu", strategy: str = "ddp", devices="auto",
+                 num_nodes: int = 1, sync_batchnorm: bool = False, val_check_interval=None, **config_updates):
+        from model.multimodal_bridge_matching import MultiModalBridgeMatching
+        self.world, self.rank, self.local = _dist_env()
+        if not torch.cuda.is_available():
+            raise RuntimeError("ExperimentPipeline needs an MI355X: the HIP path has no CPU fallback")
+        torch.cuda.set_device(self.local)
+        self.device = torch.device("cuda", self.local)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                dist.init_process_group("nccl", device_id=self.device)
+            self.dist = dist
+        self.ckpt_path = None
+        if experiment_path is not None:
+            self.experiment_path = experiment_path
+            self.ckpt_path = os.path.join(experiment_path, "checkpoints", f"{load_ckpt}.ckpt")
+            blob = torch.load(self.ckpt_path, map_location="cpu", weights_only=True)
+            self.config = ExperimentConfigs(blob["config"])
+            self.config.update(config_updates or {})
+            self.model = MultiModalBridgeMatching(self.config)
+            self.model.load_state_dict(blob["state_dict"])
+            self._resume = blob
+        else:
+            self.config = config if isinstance(config, ExperimentConfigs) else ExperimentConfigs(config)
+            self.config.update(config_updates or {})
+            self.experiment_path = self.config.path or self.config.checkpoints.dirpath
+            self.model = MultiModalBridgeMatching(self.config)
+            self._resume = None
+        self.model.to(self.device)
+        self.model.manual_seed(0xA0A0, self.rank)
+        if self.dist is not None:                                  # identical initial weights on every rank
+            for p in self.model.parameters():
+                self.dist.broadcast(p.data, src=0)
+        self.datamodule = datamodule_cls(self.config) if datamodule_cls is not None else None
+        self.history = []
+
+    # ------------------------------------------------------------------ training
+    def _log(self, rec):
+        self.history.append(rec)
+        if self.rank == 0 and self.experiment_path:
+            os.makedirs(self.experiment_path, exist_ok=True)
+            with open(os.path.join(self.experiment_path, "metrics.jsonl"), "a") as fh:
+                fh.write(json.dumps(rec) + "\n")
+
+    def _save(self, name, epoch, optimizer, scheduler):
+        if self.rank != 0 or not self.experiment_path:
+            return
+        d = os.path.join(self.experiment_path, "checkpoints")
+        os.makedirs(d, exist_ok=True)
+        torch.save({"state_dict": {k: v.cpu() for k, v in self.model.state_dict().items()},
+                    "optimizer": optimizer.state_dict(),
+                    "scheduler": scheduler.state_dict() if scheduler else None, "epoch": epoch,
+                    "config": self.config.to_dict()}, os.path.join(d, f"{name}.ckpt"))
+
+    def train(self):
+        cfg = self.config
+        model = self.model.train()
+        opt = model.configure_optimizers()
+        sched = None
+        if isinstance(opt, tuple) or isinstance(opt, list):
+            opt, sched = opt[0][0], opt[1][0]
+        flat = FlatGrads(model.parameters())
+        start = 0
+        if self._resume is not None:
+            opt.load_state_dict(self._resume["optimizer"])
+            if sched is not None and self._resume.get("scheduler"):
+                sched.load_state_dict(self._resume["scheduler"])
+            start = int(self._resume["epoch"]) + 1
+        self.datamodule.setup("fit", rank=self.rank, world=self.world, device=self.device)
+        best = float("inf")
+        for epoch in range(start, cfg.trainer.max_epochs):
+            model.train()
+            acc = torch.zeros(3, device=self.device)
+            n = 0
+            for batch in self.datamodule.train_dataloader():
+                flat.zero()
+                out = model.training_step(batch, n)
+                out["loss"].backward()
+                flat.all_reduce_mean(self.dist, self.world)
+                flat.clip_(cfg.trainer.gradient_clip_val)
+                opt.step()
+                acc += torch.stack([out["loss"].detach(), out["train_loss_continuous"], out["train_loss_discrete"]])
+                n += 1
+            if sched is not None:
+                sched.step()
+            val = torch.zeros(1, device=self.device)
+            nv = 0
+            model.eval()
+            for batch in self.datamodule.val_dataloader():
+                val += model.validation_step(batch, nv)["val_loss"]
+                nv += 1
+            stats = torch.cat([acc / max(n, 1), val / max(nv, 1)])
+            if self.dist is not None:
+                self.dist.all_reduce(stats)
+                stats /= self.world
+            tl, tc, td, vl = [float(v) for v in stats.tolist()]       # one host sync per EPOCH
+            self._log({"epoch": epoch, "train_loss": tl, "train_loss_continuous": tc, "train_loss_discrete": td,
+                       "val_loss": vl, "lr": opt.param_groups[0]["lr"]})
+            if nv and vl < best:
+                best = vl
+                self._save("best", epoch, opt, sched)
+            self._save("last", epoch, opt, sched)
+        return self.history
+
+    # ------------------------------------------------------------------ generation
+    @torch.no_grad()
+    def generate(self, gather=True):
+        """Each rank generates its shard of the test jets; rank 0 receives the concatenation."""
+        model = self.model.eval()
+        self.datamodule.setup("predict", rank=self.rank, world=self.world, device=self.device)
+        outs = []
+        for i, batch in enumerate(self.datamodule.predict_dataloader()):
+            paths, _ = model.predict_step(batch, i, to_cpu=False)
+            outs.append(paths[1])
+        gen = TensorMultiModal.cat(outs, dim=0)
+        if gather and self.dist is not None:
+            parts = [None] * self.world
+            self.dist.all_gather_object(parts, gen.cpu())
+            gen = TensorMultiModal.cat(parts, dim=0) if self.rank == 0 else None
+        if self.rank == 0 and gen is not None and self.experiment_path:
+            os.makedirs(self.experiment_path, exist_ok=True)
+            gen.cpu().save_to(os.path.join(self.experiment_path, "generated_sample.h5"))
+        return gen
+
+
+def bench_training(model, config, B, device, dist, steps=10, warmup=3):
+    """Training jets/s: K-A bridge sampling -> taped encoder forward -> K-F loss -> HIP backward ->
+    flat-bucket all-reduce -> clip -> AdamW, on a resident synthetic AOJ-shaped batch."""
+    from datamodules.synthetic import synthetic_target
+    world, rank, _ = _dist_env()
+    was_training = model.training
+    model.train()
+    tgt = synthetic_target(B, config.data.max_num_particles, config.data.target_path, seed=1234 + rank,
+                           Dc=max(config.data.dim_continuous, 1), V=config.data.vocab_size,
+                           modality=config.data.modality, device=device)
+    opt = torch.optim.AdamW(model.parameters(), **{k: v for k, v in config.trainer.optimizer_params.items()})
+    flat = FlatGrads(model.parameters())
+
+    def step(i):
+        flat.zero()
+        batch = DataCoupling(TensorMultiModal(), TensorMultiModal(None, tgt.continuous, tgt.discrete, tgt.mask), None)
+        out = model.training_step(batch, i)
+        out["loss"].backward()
+        flat.all_reduce_mean(dist, world)
+        flat.clip_(config.trainer.gradient_clip_val)
+        opt.step()
+        return out["loss"]
+
+    for i in range(warmup):
+        step(i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    model.train(was_training)
+    for p in model.parameters():
+        p.grad = None
+    return {"value": B * world * steps / dt, "unit": "jets/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "global_batch": B * world, "dropout": config.encoder.dropout, "final_loss": float(loss),
+            "includes": "bridge sampling, fwd, loss, bwd, grad all-reduce, clip, AdamW"}

@@ -256,6 +256,34 @@ int mmb_grad_weight(int M, int rows_per_jet, int n_seg,
                     const float* dZ, int64_t dz_ld, int Nout, float* dW, int64_t dw_ld, float* db,
                     void* stream);
 
+/* ---------------------------------------------------------------- K-E fused (generation) */
+/* Whole MultiModalEPiC forward (multimodal_epic.py:158-194 incl. embedder.py:74-80) for one jet
+ * per workgroup with activations resident in registers; `packed`/`desc` come from
+ * mmb_hip.fused.pack_model (weight-normed effective weights in MFMA fragment order + transposed
+ * per-jet matrices).  variant 0: S3 widths (Et32 Ec16 Ed16 H64/64/128 G16/16/32); variant 1:
+ * Et16 Ec8 Ed8 H32/32/64 G8/8/16.  N <= 128, Dc = 3, V = 8.  temb: (B,Et) with row stride
+ * temb_stride (0 = one row shared by all jets).  which: 0 continuous head, 1 discrete head, 2 both. */
+int mmb_fused_epic_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
+                           int nb_branch, int nb_fused_exec, int use_skip,
+                           int off_cw, int off_cb, int off_table,
+                           const float* maskf, const int32_t* counts,
+                           const float* x, const int64_t* k, const float* temb, int64_t temb_stride,
+                           int which, float* head_c, float* head_d, void* stream);
+
+/* simulate_dynamics (multimodal_bridge_matching.py:227-259) in ONE launch: per grid point
+ * [forward -> Euler step on x (solvers.py:21-25)] [forward -> telegraph rates (bridges.py:137-163)
+ * -> tau-leap jump (solvers.py:59-81)], final k = argmax of the last rates.  x (B,N,3) and k (B,N)
+ * are updated in place; padded slots move like real ones (K3).  times (steps) and temb_steps
+ * (steps,Et) are device arrays; delta_n (steps,B,N,V) injected Poisson counts or NULL for the
+ * Philox jump sampler (seed, offset). */
+int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, const int32_t* desc,
+                            int nb_branch, int nb_fused_exec, int use_skip,
+                            int off_cw, int off_cb, int off_table,
+                            const float* maskf, const int32_t* counts, float* x, int64_t* k,
+                            int steps, const float* times, const float* temb_steps, float dt,
+                            int thermo_kind, float gamma, const float* delta_n,
+                            uint64_t seed, uint64_t offset, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

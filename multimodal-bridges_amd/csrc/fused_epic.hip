@@ -1,0 +1,596 @@
+// K-E fused: the whole MultiModalEPiC forward -- and the whole generation loop -- for one jet
+// inside one workgroup, activations never leaving the register file.
+// Reference: encoders/multimodal_epic.py:158-194, encoders/epic.py:71-107,145-159,187-208,
+// encoders/embedder.py:63-83, model/solvers.py:21-25,59-81, model/multimodal_bridge_matching.py:227-259.
+//
+// Layout (gfx950, wave64).  One 256-thread workgroup = one jet of N <= 128 particles; wave w owns
+// particles [32w, 32w+32).  Activations are kept TRANSPOSED (features x particles) in the C/D
+// layout of v_mfma_f32_32x32x2_f32: a 32-feature tile is one f32x16 per lane, lane&31 = particle,
+// register r / lane half h = feature (r&3) + 8(r>>2) + 4h.  A layer Y^T = W X^T then needs NO data
+// movement between layers: register r of an input tile IS the B operand of k-step r (its two lane
+// halves carry the two k values of the step), and the A operand is the weight fragment
+// W[o][k(r,h)], pre-packed on the host so that one dwordx4 per lane feeds four k-steps and a wave
+// reads 1 KiB contiguous.  Per-jet inputs of a layer (time embedding x mask, global vector, bias)
+// are NOT run through the MFMA: they are a per-jet matvec c,d done once per layer by the 256
+// threads and enter as the accumulator's initial value  m[p]*c[o] + d[o]  (25 % fewer MFMA flops
+// than the concatenated formulation, same result up to fp32 summation order).
+// Masked mean/sum pooling is a DPP reduction over the 32 particle lanes + an LDS combine of the 4
+// waves.  The per-jet MLPs (M = 1 row) are VALU matvecs over transposed weights.
+#include "common.h"
+#include <utility>
+
+namespace mmb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int I> struct IF { static constexpr int v = I; };
+template <typename F, int... Is>
+__device__ __forceinline__ void ffor_impl(F&& f, std::integer_sequence<int, Is...>) { (f(IF<Is>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void ffor(F&& f) { ffor_impl(f, std::make_integer_sequence<int, N>{}); }
+
+constexpr int FE_THREADS = 256;
+
+// ------------------------------------------------------------------ small helpers ------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+// sum over the 32 lanes that share (lane >> 5); every lane of the half ends up with the sum
+__device__ __forceinline__ float half_sum32(float v) {
+  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]  (xor 1)
+  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]  (xor 2)
+  v += dpp_mov<0x141>(v);    // row_half_mirror      (other quad of the 8)
+  v += dpp_mov<0x140>(v);    // row_mirror           (other 8 of the 16)
+  v += __shfl_xor(v, 16, 64);
+  return v;
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float lrelu_f(float x) { return x > 0.0f ? x : 0.01f * x; }
+template <int ACT>
+__device__ __forceinline__ float act_f(float x) {
+  if constexpr (ACT == MMB_ACT_GELU) return gelu_f(x);
+  if constexpr (ACT == MMB_ACT_LRELU) return lrelu_f(x);
+  return x;
+}
+
+// per-layer descriptor: offsets (in floats) into the packed parameter buffer, -1 = absent
+struct LDesc {
+  int wx;   // MFMA part, packed [KT][4][OT][64][4]        (per-particle layers)
+  int wt;   // transposed [Kt][O]: time part (per-particle layers) or the whole W^T (per-jet layers)
+  int wg;   // transposed [G][O]: global-vector part
+  int b;    // bias [O] (padded to a multiple of 32 for per-particle layers)
+};
+
+struct alignas(16) Lds {
+  float temb[128];
+  float gcur[64], gskip[64], gnew[64], gcat[64];
+  float pooled[2 * 128 + 128];
+  float partial[4 * 128];
+  float scratch[FE_THREADS];
+  float gh[128];
+  float cvec[128], dvec[128];
+  float cw[32 * 4], cb[32];       // continuous embedding weight [Ec][Dc<=4], bias
+  float table[32 * 32];           // discrete embedding table [V<=32][Ed<=32]
+  float cnt;
+  int red[4];
+};
+
+// out[o] = act( sum_k WT[k*O+o] * v[k] + bias[o] ) + add[o]   -- v/out/add live in LDS
+template <int ACT>
+__device__ void matvec(const float* __restrict__ WT, const float* __restrict__ bias, const float* v, int K, int O,
+                       float* out, const float* add, float* scratch, int tid) {
+  int P = FE_THREADS / O;
+  if (P > 16) P = 16;
+  const int o = tid % O, part = tid / O;
+  if (part < P) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = part;
+    for (; k + 3 * P < K; k += 4 * P) {
+      s0 += WT[(int64_t)k * O + o] * v[k];
+      s1 += WT[(int64_t)(k + P) * O + o] * v[k + P];
+      s2 += WT[(int64_t)(k + 2 * P) * O + o] * v[k + 2 * P];
+      s3 += WT[(int64_t)(k + 3 * P) * O + o] * v[k + 3 * P];
+    }
+    for (; k < K; k += P) s0 += WT[(int64_t)k * O + o] * v[k];
+    scratch[part * O + o] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  if (tid < O) {
+    float t = bias ? bias[tid] : 0.0f;
+    for (int p = 0; p < P; ++p) t += scratch[p * O + tid];
+    t = act_f<ACT>(t);
+    if (add) t += add[tid];
+    out[tid] = t;
+  }
+  __syncthreads();
+}
+
+// acc[ot] += W_x (tile rows ot) * X^T, X^T tiles delivered by `tile(IF<ft>)`.
+template <int KT, int OT, typename TileFn>
+__device__ __forceinline__ void mma_x(f32x16 (&acc)[OT], TileFn&& tile, const float* __restrict__ Wp, int lane) {
+  const float4* w4 = reinterpret_cast<const float4*>(Wp) + lane;
+  float4 a_cur[OT], a_nxt[OT];
+  ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; a_cur[ot] = w4[ot * 64]; });
+  ffor<KT * 4>([&](auto gc) {
+    constexpr int g = decltype(gc)::v;          // group = (ft, q): four k-steps r = 4q..4q+3
+    constexpr int ft = g / 4, q = g % 4;
+    if constexpr (g + 1 < KT * 4)
+      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; a_nxt[ot] = w4[((g + 1) * OT + ot) * 64]; });
+    const f32x16& xt = tile(IF<ft>{});
+    ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+      acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ot].x, xt[4 * q + 0], acc[ot], 0, 0, 0); });
+    ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+      acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ot].y, xt[4 * q + 1], acc[ot], 0, 0, 0); });
+    ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+      acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ot].z, xt[4 * q + 2], acc[ot], 0, 0, 0); });
+    ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+      acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ot].w, xt[4 * q + 3], acc[ot], 0, 0, 0); });
+    if constexpr (g + 1 < KT * 4)
+      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; a_cur[ot] = a_nxt[ot]; });
+  });
+}
+
+// acc[ot][r] = m * c[f] + d[f]  (c, d in LDS or global; either may be null)
+template <int OT>
+__device__ __forceinline__ void acc_init(f32x16 (&acc)[OT], float m, const float* c, const float* d, int half) {
+  ffor<OT>([&](auto oc) {
+    constexpr int ot = decltype(oc)::v;
+    ffor<4>([&](auto qc) {
+      constexpr int q = decltype(qc)::v;
+      const int f = 32 * ot + 8 * q + 4 * half;
+      float4 cv = c ? *reinterpret_cast<const float4*>(c + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 dv = d ? *reinterpret_cast<const float4*>(d + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+      acc[ot][4 * q + 0] = m * cv.x + dv.x;
+      acc[ot][4 * q + 1] = m * cv.y + dv.y;
+      acc[ot][4 * q + 2] = m * cv.z + dv.z;
+      acc[ot][4 * q + 3] = m * cv.w + dv.w;
+    });
+  });
+}
+
+template <int OT, int ACT>
+__device__ __forceinline__ void act_tiles(f32x16 (&a)[OT]) {
+  ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+    ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; a[ot][r] = act_f<ACT>(a[ot][r]); }); });
+}
+
+template <int HT>
+__device__ __forceinline__ void pool_partials(const f32x16 (&x)[HT], float m, float* partial, int wave, int lane) {
+  const int half = lane >> 5;
+  ffor<HT>([&](auto tc) {
+    constexpr int t = decltype(tc)::v;
+    ffor<16>([&](auto rc) {
+      constexpr int r = decltype(rc)::v;
+      float v = half_sum32(x[t][r] * m);
+      if ((lane & 31) == 0) partial[wave * 128 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half] = v;
+    });
+  });
+}
+
+// pooled = [sum/cnt, 0.01*sum, tail]   (epic.py:100-107)
+__device__ __forceinline__ void build_pooled(int H, int T, const float* tail, Lds& L, int tid) {
+  __syncthreads();
+  if (tid < H) {
+    const float s = (L.partial[tid] + L.partial[128 + tid]) + (L.partial[256 + tid] + L.partial[384 + tid]);
+    L.pooled[tid] = s / L.cnt;
+    L.pooled[H + tid] = s * 0.01f;
+  }
+  if (tid < T) L.pooled[2 * H + tid] = tail[tid];
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------ one EPiC encoder ----
+// x: HT tiles (in/out), skip: HT tiles.  Global vector in L.gcur.  `li` walks the descriptors.
+template <int HT, int ET>
+struct Epic {
+  static constexpr int H = 32 * HT;
+
+  // EPiCLayer (epic.py:187-208) + the encoder-level skip add (:89-90)
+  static __device__ __forceinline__ void layer(f32x16 (&x)[HT], const f32x16 (&skip)[HT], bool use_skip, int G,
+                                               const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
+                                               float m, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const LDesc g1 = D[li], g2 = D[li + 1], l1 = D[li + 2], l2 = D[li + 3];
+    li += 4;
+    pool_partials<HT>(x, m, L.partial, wave, lane);
+    build_pooled(H, G, L.gcur, L, tid);
+    matvec<MMB_ACT_LRELU>(P + g1.wt, P + g1.b, L.pooled, 2 * H + G, H, L.gh, nullptr, L.scratch, tid);
+    matvec<MMB_ACT_NONE>(P + g2.wt, P + g2.b, L.gh, H, G, L.gnew, L.gcur, L.scratch, tid);   // g' = g + fc_glob2(.)
+    matvec<MMB_ACT_NONE>(P + l1.wt, nullptr, L.temb, ET, H, L.cvec, nullptr, L.scratch, tid);
+    matvec<MMB_ACT_NONE>(P + l1.wg, P + l1.b, L.gnew, G, H, L.dvec, nullptr, L.scratch, tid);
+    if (tid < G) L.gcur[tid] = lrelu_f(L.gnew[tid]) + (use_skip ? L.gskip[tid] : 0.0f);
+    f32x16 lh[HT];
+    acc_init<HT>(lh, m, L.cvec, L.dvec, half);
+    mma_x<HT, HT>(lh, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, P + l1.wx, lane);
+    act_tiles<HT, MMB_ACT_LRELU>(lh);
+    f32x16 a2[HT];
+    acc_init<HT>(a2, 0.0f, nullptr, P + l2.b, half);
+    mma_x<HT, HT>(a2, [&](auto fc) -> const f32x16& { return lh[decltype(fc)::v]; }, P + l2.wx, lane);
+    ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+      ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v;
+        const float v = lrelu_f(x[t][r] + a2[t][r]);
+        x[t][r] = use_skip ? v + skip[t][r] : v; }); });
+    __syncthreads();                                   // gcur settled before the next pooled build
+  }
+
+  // output layer: wn Linear on cat[t, x, g] (epic.py:93-96)
+  static __device__ __forceinline__ void output(f32x16 (&out)[HT], const f32x16 (&x)[HT], int G,
+                                                const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
+                                                float m, int tid) {
+    const int lane = tid & 63, half = lane >> 5;
+    const LDesc o = D[li];
+    li += 1;
+    matvec<MMB_ACT_NONE>(P + o.wt, nullptr, L.temb, ET, H, L.cvec, nullptr, L.scratch, tid);
+    matvec<MMB_ACT_NONE>(P + o.wg, P + o.b, L.gcur, G, H, L.dvec, nullptr, L.scratch, tid);
+    acc_init<HT>(out, m, L.cvec, L.dvec, half);
+    mma_x<HT, HT>(out, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, P + o.wx, lane);
+  }
+
+  // EPiCProjection (epic.py:145-159) from ONE padded input tile
+  static __device__ __forceinline__ void project(f32x16 (&x)[HT], const f32x16& xin, int G,
+                                                 const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
+                                                 float m, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const LDesc p0 = D[li], p2 = D[li + 1], q0 = D[li + 2], q2 = D[li + 3];
+    li += 4;
+    matvec<MMB_ACT_NONE>(P + p0.wt, nullptr, L.temb, ET, H, L.cvec, nullptr, L.scratch, tid);
+    f32x16 h[HT];
+    acc_init<HT>(h, m, L.cvec, P + p0.b, half);
+    mma_x<1, HT>(h, [&](auto) -> const f32x16& { return xin; }, P + p0.wx, lane);
+    act_tiles<HT, MMB_ACT_GELU>(h);
+    acc_init<HT>(x, 0.0f, nullptr, P + p2.b, half);
+    mma_x<HT, HT>(x, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, P + p2.wx, lane);
+    act_tiles<HT, MMB_ACT_GELU>(x);
+    pool_partials<HT>(x, m, L.partial, wave, lane);
+    build_pooled(H, ET, L.temb, L, tid);               // context = time embedding (dim_context = Et)
+    matvec<MMB_ACT_GELU>(P + q0.wt, P + q0.b, L.pooled, 2 * H + ET, H, L.gh, nullptr, L.scratch, tid);
+    matvec<MMB_ACT_GELU>(P + q2.wt, P + q2.b, L.gh, H, G, L.gcur, nullptr, L.scratch, tid);
+  }
+};
+
+// ------------------------------------------------------------------ model dimensions ----
+template <int ET_, int EC_, int ED_, int HB_, int GB_, int DC_, int V_>
+struct Dims {
+  static constexpr int ET = ET_, EC = EC_, ED = ED_, HB = HB_, GB = GB_, DC = DC_, V = V_;
+  static constexpr int HBT = HB / 32;          // tiles per branch
+  static constexpr int HFT = 2 * HBT;          // tiles of the fused encoder
+  static constexpr int GF = 2 * GB;
+};
+
+struct FusedArgs {
+  const float* P;          // packed parameters
+  const LDesc* D;          // layer descriptors
+  int nb_branch, nb_fused_exec, use_skip;
+  int emb_cw, emb_cb, emb_table;      // offsets into P
+  int B, N;
+  const float* maskf;      // (B,N)
+  const int32_t* counts;   // (B)
+};
+
+// embedded inputs of one particle as padded 32-feature tiles (embedder.py:74-80 + apply_mask)
+template <class DM>
+__device__ __forceinline__ void embed_tiles(f32x16& tc, f32x16& td, const float (&xp)[4], int kp, float m, const Lds& L,
+                                            int half) {
+  ffor<16>([&](auto rc) {
+    constexpr int r = decltype(rc)::v;
+    const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
+    float c = 0.0f, d = 0.0f;
+    if (f < DM::EC) {
+      float s = 0.0f;
+#pragma unroll
+      for (int dd = 0; dd < DM::DC; ++dd) s += xp[dd] * L.cw[f * 4 + dd];
+      c = (s + L.cb[f]) * m;
+    }
+    if (f < DM::ED) d = truncf(L.table[kp * 32 + f] * m);           // quirk Q1
+    tc[r] = c;
+    td[r] = d;
+  });
+}
+
+// Whole MultiModalEPiC forward for this jet.  which: 0 continuous head, 1 discrete head, 2 both.
+// hc: tile whose features 0..DC-1 are the drift; hd: tile whose features 0..V-1 are the logits.
+template <class DM>
+__device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, const float (&xp)[4], int kp, float m, int which,
+                                            f32x16& hc, f32x16& hd, int tid) {
+  constexpr int HBT = DM::HBT, HFT = DM::HFT;
+  const int lane = tid & 63, half = lane >> 5;
+  int li = 0;
+  f32x16 tc, td;
+  embed_tiles<DM>(tc, td, xp, kp, m, L, half);
+  f32x16 skip[HFT];                 // = cat[h1, h2]: fused-encoder input AND its skip connection
+  // ---- two branch encoders (multimodal_epic.py:173-175)
+  ffor<2>([&](auto bc) {
+    constexpr int br = decltype(bc)::v;
+    f32x16 x[HBT], sk[HBT], out[HBT];
+    Epic<HBT, DM::ET>::project(x, br == 0 ? tc : td, DM::GB, A.P, A.D, li, L, m, tid);
+    if (tid < DM::GB) L.gskip[tid] = L.gcur[tid];
+    ffor<HBT>([&](auto t) { sk[decltype(t)::v] = x[decltype(t)::v]; });
+    __syncthreads();
+    for (int i = 0; i < A.nb_branch; ++i)
+      Epic<HBT, DM::ET>::layer(x, sk, A.use_skip != 0, DM::GB, A.P, A.D, li, L, m, tid);
+    Epic<HBT, DM::ET>::output(out, x, DM::GB, A.P, A.D, li, L, m, tid);
+    ffor<HBT>([&](auto t) { skip[br * HBT + decltype(t)::v] = out[decltype(t)::v]; });
+    if (tid < DM::GB) L.gcat[br * DM::GB + tid] = L.gcur[tid];
+    __syncthreads();
+  });
+  // ---- fused encoder, no projection (K2: nb_fused_exec = constructed - 1)
+  if (tid < DM::GF) { L.gcur[tid] = L.gcat[tid]; L.gskip[tid] = L.gcat[tid]; }
+  __syncthreads();
+  f32x16 x[HFT], f[HFT];
+  ffor<HFT>([&](auto t) { x[decltype(t)::v] = skip[decltype(t)::v]; });
+  for (int i = 0; i < A.nb_fused_exec; ++i)
+    Epic<HFT, DM::ET>::layer(x, skip, A.use_skip != 0, DM::GF, A.P, A.D, li, L, m, tid);
+  Epic<HFT, DM::ET>::output(f, x, DM::GF, A.P, A.D, li, L, m, tid);
+  // ---- heads (multimodal_epic.py:187-189): cat[t, f_i, h_i] -> GELU -> out
+  const LDesc c0 = A.D[li], c2 = A.D[li + 1], d0 = A.D[li + 2], d2 = A.D[li + 3];
+  if (which != 1) {
+    matvec<MMB_ACT_NONE>(A.P + c0.wt, nullptr, L.temb, DM::ET, DM::HB, L.cvec, nullptr, L.scratch, tid);
+    f32x16 h[HBT];
+    acc_init<HBT>(h, m, L.cvec, A.P + c0.b, half);
+    mma_x<HFT, HBT>(h, [&](auto fc) -> const f32x16& {
+      constexpr int t = decltype(fc)::v;
+      if constexpr (t < HBT) return f[t]; else return skip[t - HBT]; }, A.P + c0.wx, lane);
+    act_tiles<HBT, MMB_ACT_GELU>(h);
+    f32x16 o[1];
+    acc_init<1>(o, 0.0f, nullptr, A.P + c2.b, half);
+    mma_x<HBT, 1>(o, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, A.P + c2.wx, lane);
+    hc = o[0];
+  }
+  if (which != 0) {
+    matvec<MMB_ACT_NONE>(A.P + d0.wt, nullptr, L.temb, DM::ET, DM::HB, L.cvec, nullptr, L.scratch, tid);
+    f32x16 h[HBT];
+    acc_init<HBT>(h, m, L.cvec, A.P + d0.b, half);
+    mma_x<HFT, HBT>(h, [&](auto fc) -> const f32x16& {
+      constexpr int t = decltype(fc)::v;
+      if constexpr (t < HBT) return f[HBT + t]; else return skip[t]; }, A.P + d0.wx, lane);
+    act_tiles<HBT, MMB_ACT_GELU>(h);
+    f32x16 o[1];
+    acc_init<1>(o, 0.0f, nullptr, A.P + d2.b, half);
+    mma_x<HBT, 1>(o, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, A.P + d2.wx, lane);
+    hd = o[0];
+  }
+}
+
+template <class DM>
+__device__ __forceinline__ void load_constants(const FusedArgs& A, Lds& L, int tid) {
+  for (int i = tid; i < DM::EC * 4; i += FE_THREADS) {
+    const int f = i >> 2, d = i & 3;
+    L.cw[i] = d < DM::DC ? A.P[A.emb_cw + f * DM::DC + d] : 0.0f;
+  }
+  for (int i = tid; i < DM::EC; i += FE_THREADS) L.cb[i] = A.P[A.emb_cb + i];
+  for (int i = tid; i < DM::V * 32; i += FE_THREADS) {
+    const int v = i >> 5, e = i & 31;
+    L.table[i] = e < DM::ED ? A.P[A.emb_table + v * DM::ED + e] : 0.0f;
+  }
+}
+
+// gather the 8 (V) logits of this lane's particle: features 0..3 sit in lane half 0, 4..7 in half 1
+template <class DM>
+__device__ __forceinline__ void gather_logits(const f32x16& hd, float (&lg)[DM::V], int lane) {
+  static_assert(DM::V == 8, "fused path is instantiated for vocab_size 8");
+  const int half = lane >> 5;
+  float mine[4] = {hd[0], hd[1], hd[2], hd[3]};
+  float other[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) other[i] = __shfl_xor(mine[i], 32, 64);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    lg[i] = half == 0 ? mine[i] : other[i];
+    lg[4 + i] = half == 0 ? other[i] : mine[i];
+  }
+}
+
+// ---- single forward: heads to HBM (validation / parity / training-forward of eval mode) ----
+template <class DM>
+__global__ void __launch_bounds__(FE_THREADS, 1)
+fused_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64_t* __restrict__ k,
+                     const float* __restrict__ temb, int64_t temb_stride, int which, float* __restrict__ head_c,
+                     float* __restrict__ head_d) {
+  __shared__ Lds L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  load_constants<DM>(A, L, tid);
+  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+    __syncthreads();
+    if (tid < DM::ET) L.temb[tid] = temb[(int64_t)b * temb_stride + tid];
+    if (tid == 0) L.cnt = (float)A.counts[b];
+    const int p = 32 * wave + (lane & 31);
+    const bool valid = p < A.N;
+    const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
+    const float m = valid ? A.maskf[gp] : 0.0f;
+    float xp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < DM::DC; ++d) xp[d] = valid ? x[gp * DM::DC + d] : 0.0f;
+    const int kp = valid ? (int)k[gp] : 0;
+    __syncthreads();
+    f32x16 hc, hd;
+    forward_jet<DM>(A, L, xp, kp, m, which, hc, hd, tid);
+    if (valid && which != 1 && half == 0) {
+#pragma unroll
+      for (int d = 0; d < DM::DC; ++d) head_c[gp * DM::DC + d] = hc[d];       // features 0..2 = regs 0..2, half 0
+    }
+    if (valid && which != 0) {
+      float lg[DM::V];
+      gather_logits<DM>(hd, lg, lane);
+      if (half == 0) {
+#pragma unroll
+        for (int v = 0; v < DM::V; ++v) head_d[gp * DM::V + v] = lg[v];
+      }
+    }
+  }
+}
+
+// ---- the whole generation loop (multimodal_bridge_matching.py:227-259) --------------------
+struct GenArgs {
+  int steps;
+  const float* times;        // (steps) grid points (host linspace, fp32)
+  const float* temb_steps;   // (steps, ET) time embedding per grid point (identical for every jet)
+  float dt;
+  int thermo_kind;
+  float thermo_c;            // fp32(-V*gamma)
+  const float* delta_n;      // (steps,B,N,V) injected Poisson counts or NULL -> Philox
+  uint64_t seed, offset;
+};
+
+__device__ __forceinline__ float thermo_w_f(int kind, float c, float t0, float t1) { return thermo_w(kind, c, t0, t1); }
+
+template <class DM>
+__global__ void __launch_bounds__(FE_THREADS, 1)
+fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* __restrict__ k) {
+  __shared__ Lds L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  constexpr int V = DM::V;
+  load_constants<DM>(A, L, tid);
+  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+    __syncthreads();
+    if (tid == 0) L.cnt = (float)A.counts[b];
+    const int p = 32 * wave + (lane & 31);
+    const bool valid = p < A.N;
+    const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
+    const float m = valid ? A.maskf[gp] : 0.0f;
+    float xp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < DM::DC; ++d) xp[d] = valid ? x[gp * DM::DC + d] : 0.0f;
+    int kp = valid ? (int)k[gp] : 0;
+    for (int s = 0; s < Gn.steps; ++s) {
+      __syncthreads();
+      if (tid < DM::ET) L.temb[tid] = Gn.temb_steps[(int64_t)s * DM::ET + tid];
+      __syncthreads();
+      const float tt = Gn.times[s];
+      f32x16 hc, hd;
+      // Euler step on the drift head (solvers.py:21-25); padded slots move too (K3)
+      forward_jet<DM>(A, L, xp, kp, m, 0, hc, hd, tid);
+      {
+        float v[3] = {hc[0], hc[1], hc[2]};
+#pragma unroll
+        for (int d = 0; d < DM::DC; ++d) {
+          const float o = __shfl_xor(v[d], 32, 64);
+          const float drift = half == 0 ? v[d] : o;
+          xp[d] += Gn.dt * drift;
+        }
+      }
+      __syncthreads();
+      // tau-leap on the logits head, which sees the UPDATED x at the same t (solvers.py:59-81)
+      forward_jet<DM>(A, L, xp, kp, m, 1, hc, hd, tid);
+      float r[V];
+      gather_logits<DM>(hd, r, lane);
+      {
+        const float w = thermo_w_f(Gn.thermo_kind, Gn.thermo_c, tt, 1.0f);
+        const float Bc = (w * (float)V) / (1.0f - w);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int v = 0; v < V; ++v) mx = fmaxf(mx, r[v]);
+        float sum = 0.0f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) { r[v] = expf(r[v] - mx); sum += r[v]; }
+        float qk = 0.0f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) { r[v] = r[v] / sum; qk = (v == kp) ? r[v] : qk; }
+#pragma unroll
+        for (int v = 0; v < V; ++v) r[v] = 1.0f + Bc * r[v] + w * qk;
+      }
+      if (s == Gn.steps - 1) {                           // final state: argmax of the last rates (:253-255)
+        int best = 0;
+        float bv = r[0];
+#pragma unroll
+        for (int v = 1; v < V; ++v) if (r[v] > bv) { bv = r[v]; best = v; }
+        kp = best;
+      } else if (Gn.delta_n != nullptr) {
+        int knew = kp;
+        if (valid) {
+          const float* dn = Gn.delta_n + (((int64_t)s * A.B + b) * A.N + p) * V;
+          float tot = 0.0f, net = 0.0f;
+#pragma unroll
+          for (int v = 0; v < V; ++v) { const float d = dn[v]; tot += d; net += d * (float)(v - kp); }
+          const int64_t ok = ((int64_t)tot <= 1) ? 1 : 0;
+          int64_t moved = (int64_t)kp + (int64_t)net * ok;
+          moved %= V;
+          if (moved < 0) moved += V;
+          knew = (int)moved;
+        }
+        kp = knew;
+      } else {
+        uint32_t q[4];
+        philox4(Gn.seed, Gn.offset + (uint64_t)s, (uint64_t)gp, 0xC001u, q);
+        const float u = u01(q[0]);
+        float Lam = 0.0f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) Lam += r[v] * Gn.dt;
+        const float e = expf(-Lam);
+        float acc = 0.0f;
+        int hit = -1;
+#pragma unroll
+        for (int v = 0; v < V; ++v) { acc += r[v] * Gn.dt * e; if (hit < 0 && u < acc) hit = v; }
+        if (hit >= 0) kp = hit;
+      }
+    }
+    if (valid && half == 0) {
+#pragma unroll
+      for (int d = 0; d < DM::DC; ++d) x[gp * DM::DC + d] = xp[d];
+      k[gp] = kp;
+    }
+  }
+}
+
+typedef Dims<32, 16, 16, 64, 16, 3, 8> DimsS3;       // configs/S3_multimodal.yaml
+typedef Dims<16, 8, 8, 32, 8, 3, 8> DimsMid;         // the mm_mid golden / small models
+
+static int check_fused(const char* name, int B, int N, const void* P, const void* D, const void* maskf,
+                       const void* counts) {
+  MMB_REQUIRE(B > 0 && N > 0 && N <= 128, "%s: needs 0 < N <= 128 (got B=%d N=%d)", name, B, N);
+  MMB_REQUIRE(P && D && maskf && counts, "%s: NULL argument", name);
+  return MMB_OK;
+}
+
+}  // namespace mmb
+
+using namespace mmb;
+
+// variant: 0 = S3 dims (Et32 Ec16 Ed16 H64/64/128 G16/16/32), 1 = "mid" dims (Et16 Ec8 Ed8 H32/32/64 G8/8/16)
+extern "C" int mmb_fused_epic_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
+                                      int nb_branch, int nb_fused_exec, int use_skip, int off_cw, int off_cb,
+                                      int off_table, const float* maskf, const int32_t* counts, const float* x,
+                                      const int64_t* k, const float* temb, int64_t temb_stride, int which,
+                                      float* head_c, float* head_d, void* stream) {
+  int rc = check_fused("mmb_fused_epic_forward", B, N, packed, desc, maskf, counts);
+  if (rc) return rc;
+  MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_epic_forward: unknown variant %d", variant);
+  MMB_REQUIRE(x && k && temb, "mmb_fused_epic_forward: NULL state");
+  MMB_REQUIRE(which >= 0 && which <= 2, "mmb_fused_epic_forward: which=%d", which);
+  if (which != 1) MMB_REQUIRE(head_c, "mmb_fused_epic_forward: head_c is NULL");
+  if (which != 0) MMB_REQUIRE(head_d, "mmb_fused_epic_forward: head_d is NULL");
+  FusedArgs A{packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
+              off_table, B, N, maskf, counts};
+  const int grid = B < 2048 ? B : 2048;
+  if (variant == 0)
+    hipLaunchKernelGGL(fused_forward_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k, temb,
+                       temb_stride, which, head_c, head_d);
+  else
+    hipLaunchKernelGGL(fused_forward_kernel<DimsMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k, temb,
+                       temb_stride, which, head_c, head_d);
+  return check_launch("mmb_fused_epic_forward");
+}
+
+extern "C" int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, const int32_t* desc,
+                                       int nb_branch, int nb_fused_exec, int use_skip, int off_cw, int off_cb,
+                                       int off_table, const float* maskf, const int32_t* counts, float* x, int64_t* k,
+                                       int steps, const float* times, const float* temb_steps, float dt,
+                                       int thermo_kind, float gamma, const float* delta_n, uint64_t seed,
+                                       uint64_t offset, void* stream) {
+  int rc = check_fused("mmb_fused_epic_generate", B, N, packed, desc, maskf, counts);
+  if (rc) return rc;
+  MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_epic_generate: unknown variant %d", variant);
+  MMB_REQUIRE(x && k && times && temb_steps && steps > 0, "mmb_fused_epic_generate: NULL state / steps");
+  MMB_REQUIRE(thermo_kind >= 0 && thermo_kind <= 4, "mmb_fused_epic_generate: bad thermostat");
+  FusedArgs A{packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
+              off_table, B, N, maskf, counts};
+  GenArgs Gn{steps, times, temb_steps, dt, thermo_kind, (float)(-(double)8 * (double)gamma), delta_n, seed, offset};
+  const int grid = B < 2048 ? B : 2048;
+  if (variant == 0)
+    hipLaunchKernelGGL(fused_generate_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k);
+  else
+    hipLaunchKernelGGL(fused_generate_kernel<DimsMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k);
+  return check_launch("mmb_fused_epic_generate");
+}

@@ -1,0 +1,161 @@
+"""Host side of the fused per-jet EPiC kernels (csrc/fused_epic.hip): eligibility check,
+parameter packing into MFMA-fragment order, and the launch wrappers.
+
+Packing (per weight-normed Linear, effective weight W = g*v/||v|| from the HIP weight-norm
+kernel):
+  x-part  W[:, x-columns]  -> zero-padded to (32*OT, 32*KT) and laid out [KT][4][OT][64][4]:
+          element (ft, q, ot, lane=(hk,i), e) = W[32ot+i][32ft + 8q + 4hk + e], i.e. exactly the
+          four consecutive k values lane (i,hk) feeds to k-steps 4q..4q+3 of input tile ft
+  t-part / g-part / per-jet matrices -> transposed [K][O] so the matvec threads read coalesced
+  bias    -> zero-padded to a multiple of 32
+Every chunk starts on a 16-byte boundary.  The layer order is the order the kernel walks.
+"""
+import ctypes as C
+
+import torch
+
+from . import call
+from .ops import f32, i32, i64, stream, _fl
+
+VARIANTS = {  # (Et, Ec, Ed, Hb, Gb) -> variant id (fused_epic.hip: DimsS3 / DimsMid)
+    (32, 16, 16, 64, 16): 0,
+    (16, 8, 8, 32, 8): 1,
+}
+
+
+def eligible(model):
+    """Variant id if the model is a branched+fused MultiModalEPiC of a compiled width set."""
+    cfg = model.config
+    e, d = cfg.encoder, cfg.data
+    if e.name != "MultiModalEPiC" or d.modality != "multi-modal":
+        return None
+    enc = model.encoder
+    if not (getattr(enc, "mode_branched", False) and getattr(enc, "mode_fused", False)):
+        return None
+    if d.dim_continuous != 3 or d.vocab_size != 8 or (d.max_num_particles or 0) > 128:
+        return None
+    H0, H1, H2, half = enc.dims
+    hl, hg = e.dim_hidden_local, e.dim_hidden_glob
+    if H0 != H1 or H2 != H0 + H1 or hg[0] != hg[1] or hg[2] != hg[0] + hg[1]:
+        return None
+    if e.num_blocks[0] != e.num_blocks[1]:
+        return None
+    if e.dim_emb_context_continuous or e.dim_emb_context_discrete:
+        return None
+    return VARIANTS.get((e.dim_emb_time, e.dim_emb_continuous, e.dim_emb_discrete, H0, hg[0]))
+
+
+class _Packer:
+    def __init__(self, device):
+        self.chunks, self.n, self.desc, self.device = [], 0, [], device
+
+    def add(self, t):
+        t = t.contiguous().reshape(-1).float()
+        off = self.n
+        pad = (-t.numel()) % 4
+        self.chunks.append(t)
+        if pad:
+            self.chunks.append(torch.zeros(pad, device=self.device))
+        self.n += t.numel() + pad
+        return off
+
+    @staticmethod
+    def pack_x(W):
+        """(O,Kx) -> MFMA fragment order, zero padded to multiples of 32."""
+        O, K = W.shape
+        OT, KT = (O + 31) // 32, (K + 31) // 32
+        Wp = torch.zeros(OT * 32, KT * 32, device=W.device)
+        Wp[:O, :K] = W
+        v = Wp.view(OT, 32, KT, 4, 2, 4)                 # (ot, i, ft, q, hk, e)
+        return v.permute(2, 3, 0, 4, 1, 5).contiguous()  # (ft, q, ot, hk, i, e)
+
+    def bias(self, b):
+        O = b.numel()
+        bp = torch.zeros((O + 31) // 32 * 32, device=b.device)
+        bp[:O] = b
+        return self.add(bp)
+
+    def particle_layer(self, lin, n_t, n_x, n_g):
+        """columns = [t (n_t) | x (n_x) | g (n_g)]"""
+        W = lin.weight()
+        wt = self.add(W[:, :n_t].t()) if n_t else -1
+        wx = self.add(self.pack_x(W[:, n_t:n_t + n_x]))
+        wg = self.add(W[:, n_t + n_x:].t()) if n_g else -1
+        self.desc.append([wx, wt, wg, self.bias(lin.bias.detach())])
+
+    def jet_layer(self, lin):
+        W = lin.weight()
+        self.desc.append([-1, self.add(W.t()), -1, self.add(lin.bias.detach())])
+
+
+def pack_model(model):
+    """-> dict(packed, desc, variant, nb_branch, nb_fused_exec, use_skip, off_cw, off_cb, off_table)."""
+    variant = eligible(model)
+    if variant is None:
+        return None
+    cfg = model.config
+    enc, emb = model.encoder, model.embedder
+    Et = cfg.encoder.dim_emb_time
+    H0, H1, H2, half = enc.dims
+    G0 = cfg.encoder.dim_hidden_glob[0]
+    dev = next(model.parameters()).device
+    pk = _Packer(dev)
+    for branch, n_in in ((enc.continuous_encoder, cfg.encoder.dim_emb_continuous),
+                         (enc.discrete_encoder, cfg.encoder.dim_emb_discrete)):
+        pr = branch.epic_proj
+        pk.particle_layer(pr.mlp_local["0"], Et, n_in, 0)
+        pk.particle_layer(pr.mlp_local["2"], 0, H0, 0)
+        pk.jet_layer(pr.mlp_global["0"])
+        pk.jet_layer(pr.mlp_global["2"])
+        for i in range(branch.num_blocks):
+            ly = branch.epic_layers[i]
+            pk.jet_layer(ly.fc_glob1)
+            pk.jet_layer(ly.fc_glob2)
+            pk.particle_layer(ly.fc_loc1, Et, H0, G0)
+            pk.particle_layer(ly.fc_loc2, 0, H0, 0)
+        pk.particle_layer(branch.output_layer, Et, H0, G0)
+    fe = enc.fused_encoder
+    for i in range(fe.num_blocks):                        # executed layers only (K2)
+        ly = fe.epic_layers[i]
+        pk.jet_layer(ly.fc_glob1)
+        pk.jet_layer(ly.fc_glob2)
+        pk.particle_layer(ly.fc_loc1, Et, H2, 2 * G0)
+        pk.particle_layer(ly.fc_loc2, 0, H2, 0)
+    pk.particle_layer(fe.output_layer, Et, H2, 2 * G0)
+    for head in (enc.continuous_head, enc.discrete_head):
+        pk.particle_layer(head["0"], Et, half + H0, 0)
+        pk.particle_layer(head["2"], 0, H0, 0)
+    off_cw = pk.add(emb.continuous_embedding.weight.detach())
+    off_cb = pk.add(emb.continuous_embedding.bias.detach())
+    off_table = pk.add(emb.discrete_embedding.table())
+    packed = torch.cat(pk.chunks)
+    desc = torch.tensor(pk.desc, dtype=torch.int32, device=dev).reshape(-1)
+    return {"packed": packed, "desc": desc, "variant": variant, "nb_branch": enc.continuous_encoder.num_blocks,
+            "nb_fused_exec": fe.num_blocks, "use_skip": int(bool(cfg.encoder.skip_connection)),
+            "off_cw": off_cw, "off_cb": off_cb, "off_table": off_table}
+
+
+def params_version(model):
+    return tuple(p._version for p in model.parameters()) + (next(model.parameters()).data_ptr(),)
+
+
+def forward(pack, mi, x, k, temb, which, temb_stride=None):
+    """-> (head_c (B,N,3) | None, head_d (B,N,8) | None)"""
+    B, N = mi.B, mi.N
+    dev = x.device
+    hc = torch.empty(B, N, 3, dtype=torch.float32, device=dev) if which != 1 else None
+    hd = torch.empty(B, N, 8, dtype=torch.float32, device=dev) if which != 0 else None
+    stride = temb.stride(0) if temb_stride is None else temb_stride
+    call("mmb_fused_epic_forward", pack["variant"], B, N, f32(pack["packed"]), i32(pack["desc"]), pack["nb_branch"],
+         pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"], pack["off_table"], f32(mi.maskf),
+         i32(mi.counts), f32(x, "x"), i64(k, "k"), f32(temb, "temb"), stride, which, f32(hc), f32(hd), stream())
+    return hc, hd
+
+
+def generate(pack, mi, x, k, times, temb_steps, dt, thermo_kind, gamma, delta_n=None, seed=0, offset=0):
+    """In-place generation loop on x (B,N,3) and k (B,N,1)."""
+    B, N = mi.B, mi.N
+    call("mmb_fused_epic_generate", pack["variant"], B, N, f32(pack["packed"]), i32(pack["desc"]), pack["nb_branch"],
+         pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"], pack["off_table"], f32(mi.maskf),
+         i32(mi.counts), f32(x, "x"), i64(k, "k"), times.numel(), f32(times, "times"), f32(temb_steps, "temb_steps"),
+         _fl(dt), thermo_kind, _fl(gamma), f32(delta_n, "delta_n"), seed, offset, stream())

@@ -316,6 +316,17 @@ def embed(t, t_scalar, x, k, mi, fourier_W, time_W, time_b, cont_W, cont_b, tabl
     return (temb, cont, disc, feat) if want_feat else (temb, cont, disc)
 
 
+def time_embed(t, fourier_W, time_W, time_b):
+    """Per-row time embedding Linear(cat[sin, cos](2 pi t W)) for a vector t (n,) -> (n, Et)."""
+    n = t.numel()
+    Et = time_W.shape[0]
+    temb = torch.empty(n, Et, dtype=torch.float32, device=t.device)
+    ones = torch.ones(n, dtype=torch.float32, device=t.device)
+    call("mmb_embed", n, 1, 0, 0, Et, 0, 0, f32(t.contiguous(), "t"), _fl(0.0), None, None, f32(ones),
+         f32(fourier_W), f32(time_W), f32(time_b), None, None, None, f32(temb), None, None, None, stream())
+    return temb
+
+
 # ------------------------------------------------------------------------ backward
 def _pl(t):
     return (t.data_ptr(), t.stride(0)) if t is not None else (None, 0)

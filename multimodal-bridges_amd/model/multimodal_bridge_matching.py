@@ -29,6 +29,7 @@ from datamodules.datasets import DataCoupling
 from encoders.embedder import MultiModalEmbedder
 from model.solvers import ContinuousSolver, DiscreteSolver
 from mmb_hip import ops
+from mmb_hip import fused as fused_epic
 
 
 class MultiModeLoss(nn.Module):
@@ -99,6 +100,8 @@ class MultiModalBridgeMatching(nn.Module):
         self.rank = 0
         self._calls = 0
         self._tape = None
+        self.use_fused = True          # per-jet fused kernels when the architecture is eligible
+        self._fused_cache = None
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -122,6 +125,19 @@ class MultiModalBridgeMatching(nn.Module):
             state._mask_info = mi
         return mi
 
+    def _fused_pack(self):
+        """Packed parameters of the fused per-jet kernels, rebuilt when a parameter changed."""
+        if not self.use_fused:
+            return None
+        ver = fused_epic.params_version(self)
+        if self._fused_cache is None or self._fused_cache[0] != ver:
+            self._fused_cache = (ver, fused_epic.pack_model(self))
+        return self._fused_cache[1]
+
+    def _time_embedding(self, t):
+        te = self.embedder.time_embedding
+        return ops.time_embed(t, te[0].W.detach(), te[1].weight.detach(), te[1].bias.detach())
+
     # ------------------------------------------------------------------ forward
     def forward(self, state: TensorMultiModal, batch: DataCoupling = None) -> TensorMultiModal:
         return self.forward_heads(state, batch, which="both")
@@ -132,6 +148,21 @@ class MultiModalBridgeMatching(nn.Module):
         mi = self._mask_info(state)
         t = getattr(state, "_t_scalar", None)
         time = state.time if t is None else t
+        inference = self._tape is None and (not self.training or not self.config.encoder.dropout)
+        pack = self._fused_pack() if (inference and state.has_continuous and state.has_discrete) else None
+        if pack is not None:
+            B = mi.B
+            if t is None:
+                tv = time.reshape(-1)
+                tv = (tv if tv.numel() == B else time.reshape(B, -1)[:, 0]).contiguous().float()
+                temb, stride = self._time_embedding(tv), None
+            else:
+                temb = self._time_embedding(torch.full((1,), float(t), device=state.mask.device))
+                stride = 0
+            w = {"continuous": 0, "discrete": 1}.get(which, 2)
+            hc, hd = fused_epic.forward(pack, mi, state.continuous.contiguous(), state.discrete.contiguous(), temb, w,
+                                        temb_stride=stride)
+            return TensorMultiModal(None, hc, hd, state.mask)
         loc = self.embedder.embed(time, state.continuous, state.discrete, state.mask, mi=mi, tape=self._tape)
         glob = TensorMultiModal(time=loc.temb)
         off = self._next_offset() if (self.training and self.config.encoder.dropout) else 0
@@ -284,6 +315,22 @@ class MultiModalBridgeMatching(nn.Module):
         if state.has_discrete:
             state.discrete = state.discrete.clone()                   # the source tokens stay intact
         mi = self._mask_info(state)
+        pack = self._fused_pack() if (state.has_continuous and state.has_discrete) else None
+        only_dn = noise is None or set(noise.keys()) <= {"delta_n"}
+        if (pack is not None and cfg.solver_continuous == "euler" and cfg.solver_discrete == "tauleap" and only_dn):
+            # ONE launch for the whole loop: per-jet workgroups keep the state in registers
+            dev = state.mask.device
+            tv = grid.to(dev)
+            dn = None
+            if noise and "delta_n" in noise:
+                dn = noise["delta_n"]
+                dn = (torch.stack(list(dn), 0) if isinstance(dn, (list, tuple)) else dn).contiguous().float()
+            br = self.bridge_discrete
+            state.continuous = state.continuous.contiguous()
+            fused_epic.generate(pack, mi, state.continuous, state.discrete, tv, self._time_embedding(tv), delta_t,
+                                br.thermo_kind, br.gamma, delta_n=dn, seed=self.seed, offset=(call_id << 16))
+            state.time = torch.full((mi.B, mi.N, 1), times[-1], device=dev)
+            return TensorMultiModal.stack([first, state], dim=0)
         was_training = self.training
         self.eval()
         rates = None

@@ -86,6 +86,17 @@ def profile_dominant_kernel(model, config, B, device):
     return groups
 
 
+def measured_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r1/pmc_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes)."""
+    path = os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh).get(workload)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(model, config, workload, n_jets, n_steps):
     """CPU oracle on a bounded sample: n_jets jets, the first n_steps of the 100-point grid."""
     from oracle import model as OM, source as OS
@@ -175,7 +186,21 @@ def main():
         dom = groups.get("mmb_linear_cat[per-particle]")
         total_ms = sum(g["ms"] for g in groups.values())
         roof = None
-        if dom:
+        fz = groups.get("mmb_fused_epic_generate")
+        if fz:
+            from mmb_hip.fused import algorithmic_flops_per_particle
+            fpp = algorithmic_flops_per_particle(model)
+            n_fwd = 2 * args.solver_steps                       # two encoder forwards per grid point
+            alg = float(fpp) * config.data.max_num_particles * B * n_fwd * fz["n"]
+            achieved = alg / (fz["ms"] * 1e-3) / 1e12
+            tr = measured_traffic(args.workload)
+            roof = {"kernel": "fused_generate_kernel (whole generation loop, fp32 MFMA 32x32x2)", "bound": "mfma",
+                    "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": tr,
+                    "launches": fz["n"], "avg_launch_us": fz["ms"] * 1e3 / fz["n"],
+                    "algorithmic_flops_per_particle_per_forward": fpp, "forwards_per_launch": n_fwd,
+                    "share_of_gpu_time": fz["ms"] / total_ms}
+        elif dom:
             achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             roof = {"kernel": "linear_cat_kernel (fp32 MFMA 32x32x2, per-particle layers)", "bound": "mfma",
                     "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

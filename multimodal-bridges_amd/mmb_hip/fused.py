@@ -159,3 +159,30 @@ def generate(pack, mi, x, k, times, temb_steps, dt, thermo_kind, gamma, delta_n=
          pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"], pack["off_table"], f32(mi.maskf),
          i32(mi.counts), f32(x, "x"), i64(k, "k"), times.numel(), f32(times, "times"), f32(temb_steps, "temb_steps"),
          _fl(dt), thermo_kind, _fl(gamma), f32(delta_n, "delta_n"), seed, offset, stream())
+
+
+def algorithmic_flops_per_particle(model):
+    """GEMM flops per particle per encoder forward AS THE REFERENCE EXECUTES IT (2*K*N over every
+    weight-normed Linear on the per-particle path, concatenated inputs included, both heads; the
+    continuous embedding adds 2*Dc*Ec).  SURVEY.md 8(d): 574 944 for S3, 1 159 424 for S2."""
+    from encoders.epic import EPiCEncoder, WNLinear
+
+    def enc_flops(e):
+        f = 0
+        if hasattr(e, "epic_proj"):
+            f += sum(2 * l.dim_in * l.dim_out for l in e.epic_proj.mlp_local.values())
+        for i in range(e.num_blocks):
+            ly = e.epic_layers[i]
+            f += 2 * ly.fc_loc1.dim_in * ly.fc_loc1.dim_out + 2 * ly.fc_loc2.dim_in * ly.fc_loc2.dim_out
+        return f + 2 * e.output_layer.dim_in * e.output_layer.dim_out
+
+    total = 0
+    for m in model.encoder.children():
+        if isinstance(m, EPiCEncoder):
+            total += enc_flops(m)
+        elif isinstance(m, torch.nn.ModuleDict):            # heads
+            total += sum(2 * l.dim_in * l.dim_out for l in m.values() if isinstance(l, WNLinear))
+    ce = getattr(model.embedder, "continuous_embedding", None)
+    if ce is not None:
+        total += 2 * ce.in_features * ce.out_features
+    return total

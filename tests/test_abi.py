@@ -47,3 +47,18 @@ def test_no_cpu_fallback():
     from mmb_hip import ops, MMBError
     with pytest.raises(MMBError):
         ops.euler_step_(torch.zeros(8), torch.zeros(8), 0.1)
+
+
+def test_algorithmic_flops_match_survey():
+    """The per-particle GEMM flop counts the roofline uses."""
+    import yaml
+    from pipeline.configs import ExperimentConfigs
+    from model.multimodal_bridge_matching import MultiModalBridgeMatching
+    from mmb_hip.fused import algorithmic_flops_per_particle, eligible
+    want = {"configs/S3_multimodal.yaml": 574944, "configs/S2_discrete.yaml": 1159424}
+    for path, flops in want.items():
+        cfg = yaml.safe_load(open(os.path.join(ROOT, path)))
+        cfg["data"]["target_path"] = os.path.join(ROOT, "tests", "golden")
+        model = MultiModalBridgeMatching(ExperimentConfigs(cfg))
+        assert algorithmic_flops_per_particle(model) == flops
+    assert eligible(model) is None            # S2 (UniModalEPiC) runs the layered path

@@ -150,7 +150,7 @@ int mmb_rate_euler_jump(int B, int N, int V, const float* logits, int64_t* k,
 
 /* ---------------------------------------------------------------- K-F loss ------------ */
 
-#define MMB_LOSS_MAX_BLOCKS 1024
+#define MMB_LOSS_MAX_BLOCKS 2048
 /* loss_fn (multimodal_bridge_matching.py:165-192) forward + gradient w.r.t. the heads in
  * one pass.  head_c (B,N,Dc) | NULL, head_d (B,N,V) | NULL.  The drift target is formed on
  * the fly from (t, xt, x0, x1) (bridges.py:30-37 / :95-103).  vocab_freq (V) | NULL.
@@ -274,13 +274,16 @@ int mmb_fused_epic_forward(int variant, int B, int N, const float* packed, const
  * [forward -> Euler step on x (solvers.py:21-25)] [forward -> telegraph rates (bridges.py:137-163)
  * -> tau-leap jump (solvers.py:59-81)], final k = argmax of the last rates.  x (B,N,3) and k (B,N)
  * are updated in place; padded slots move like real ones (K3).  times (steps) and temb_steps
- * (steps,Et) are device arrays; delta_n (steps,B,N,V) injected Poisson counts or NULL for the
+ * (steps,Et) are device arrays; ctab_steps (steps,n_ctab,128) | NULL holds the precomputed time
+ * vectors W_t temb of every layer that consumes the time embedding (t is the same for all jets
+ * of a grid point, so this per-jet matvec is hoisted out of the kernel); delta_n (steps,B,N,V) injected Poisson counts or NULL for the
  * Philox jump sampler (seed, offset). */
 int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, const int32_t* desc,
                             int nb_branch, int nb_fused_exec, int use_skip,
                             int off_cw, int off_cb, int off_table,
                             const float* maskf, const int32_t* counts, float* x, int64_t* k,
-                            int steps, const float* times, const float* temb_steps, float dt,
+                            int steps, const float* times, const float* temb_steps,
+                            const float* ctab_steps, int n_ctab, float dt,
                             int thermo_kind, float gamma, const float* delta_n,
                             uint64_t seed, uint64_t offset, void* stream);
 

@@ -139,22 +139,28 @@ grad_weight_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restr
   const int r_end = min(M, r_begin + rows_per_block);
   const bool o_ok = (o0 + i32) < Nout;
 
-  // resolve this lane's input column for each of its tiles once
+  // resolve this lane's input column for each of its tiles once.  Every (row, tile) element is
+  // ONE unconditional load from base + (per-row ? row : jet) * ld; masks and the bias column are
+  // applied when the value is consumed, so no load is followed by a dependent wait or branch.
   const float* base[NJ];
-  int ld[NJ], kind[NJ];
+  int ld[NJ];
+  bool per_row[NJ], use_mask[NJ], is_one[NJ], is_zero[NJ];
   sfor<NJ>([&](auto qc) {
     constexpr int q = decltype(qc)::v;
     const int col = (wave + 4 * q) * 32 + i32;
-    base[q] = nullptr; ld[q] = 0; kind[q] = -1;                 // -1: beyond K+1 -> zero
-    if (col == K) kind[q] = 3;                                   // bias column: constant one
+    base[q] = dZ; ld[q] = 0; per_row[q] = false; use_mask[q] = false;
+    is_one[q] = (col == K);                                      // bias column: constant one
+    is_zero[q] = (col > K);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
       if (s < sg.n && col >= sg.s[s].k_begin && col < sg.s[s].k_begin + sg.s[s].width) {
         base[q] = sg.s[s].ptr + (col - sg.s[s].k_begin);
         ld[q] = sg.s[s].ld;
-        kind[q] = sg.s[s].kind;
+        per_row[q] = sg.s[s].kind == MMB_SEG_ROW;
+        use_mask[q] = sg.s[s].kind == MMB_SEG_JET_MASK;
       }
   });
+  const float* mptr = maskf ? maskf : dZ;          // always-valid address; ignored unless use_mask
 
   f32x16 acc[NJ];
   sfor<NJ>([&](auto qc) {
@@ -163,28 +169,39 @@ grad_weight_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restr
     for (int e = 0; e < 16; ++e) acc[q][e] = 0.0f;
   });
 
+  // software pipeline: the loads of row group g+1 are in flight while group g feeds the MFMAs
+  float a_nx[U], m_nx[U];
+  float b_nx[U][NJ];
+  auto load_group = [&](int m0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = m0 + 2 * u + half;
+      const int rr = row < r_end ? row : r_end - 1;
+      a_nx[u] = dZ[(int64_t)rr * dz_ld + (o_ok ? o0 + i32 : 0)];
+      m_nx[u] = mptr[maskf ? rr : 0];
+      const int jet = rr / rows_per_jet;
+      sfor<NJ>([&](auto qc) {
+        constexpr int q = decltype(qc)::v;
+        b_nx[u][q] = base[q][(int64_t)(per_row[q] ? rr : jet) * ld[q]];
+      });
+    }
+  };
+  load_group(r_begin);
   for (int m0 = r_begin; m0 < r_end; m0 += 2 * U) {
     float a[U];
     float b[U][NJ];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int row = m0 + 2 * u + half;
-      const bool ok = row < r_end;
-      const int rr = ok ? row : r_begin;
-      a[u] = (ok && o_ok) ? dZ[(int64_t)rr * dz_ld + o0 + i32] : 0.0f;
-      const int jet = rr / rows_per_jet;
+      const float okf = (m0 + 2 * u + half) < r_end ? 1.0f : 0.0f;
+      a[u] = o_ok ? a_nx[u] * okf : 0.0f;
       sfor<NJ>([&](auto qc) {
         constexpr int q = decltype(qc)::v;
-        float v = 0.0f;
-        if (ok) {
-          if (kind[q] == MMB_SEG_ROW) v = base[q][(int64_t)rr * ld[q]];
-          else if (kind[q] == MMB_SEG_JET) v = base[q][(int64_t)jet * ld[q]];
-          else if (kind[q] == MMB_SEG_JET_MASK) v = base[q][(int64_t)jet * ld[q]] * maskf[rr];
-          else if (kind[q] == 3) v = 1.0f;
-        }
-        b[u][q] = v;
+        float v = use_mask[q] ? b_nx[u][q] * m_nx[u] : b_nx[u][q];
+        v = is_one[q] ? 1.0f : v;
+        b[u][q] = is_zero[q] ? 0.0f : v;
       });
     }
+    if (m0 + 2 * U < r_end) load_group(m0 + 2 * U);
 #pragma unroll
     for (int u = 0; u < U; ++u)
       sfor<NJ>([&](auto qc) {

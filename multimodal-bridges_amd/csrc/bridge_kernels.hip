@@ -72,6 +72,60 @@ bridge_sample_kernel(int P, int N, int Dc, int V, const float* __restrict__ t_u,
 }
 
 // Fused-RNG mode: t, source (x0,k0), z and u all come from Philox in registers.
+// Draws are distribution-level (not bit-compared with anything), so the transcendental work uses
+// the hardware approximations (v_exp/v_log/v_sin/v_cos): the kernel must stay HBM-bound.
+__device__ inline void box_muller_fast(uint32_t r0, uint32_t r1, float& n0, float& n1) {
+  const float u = u01_open0(r0);
+  const float v = u01(r1);
+  const float rad = sqrtf(-2.0f * __logf(u));
+  n0 = rad * __builtin_amdgcn_cosf(v);            // v_cos_f32 takes revolutions: cos(2 pi v)
+  n1 = rad * __builtin_amdgcn_sinf(v);
+}
+
+__device__ inline float thermo_w_fast(int kind, float c, float t0, float t1) {
+  float I;
+  switch (kind) {
+    case MMB_THERMO_CONSTANT: I = t1 - t0; break;
+    case MMB_THERMO_INVERSE: I = __logf(t1 / t0); break;
+    case MMB_THERMO_LINEAR: I = (t1 * t1 - t0 * t0) * 0.5f; break;
+    case MMB_THERMO_INVERSE_SQUARE: I = (t1 - t0) / (t1 * t0); break;
+    default: I = tanhf(t1 * 0.5f) - tanhf(t0 * 0.5f); break;
+  }
+  return __expf(c * I);
+}
+
+// posterior draw without the common 1/p3 factor (the inverse CDF is scale invariant)
+__device__ inline int telegraph_draw_fast(float w_t1, float w_0t, float invV, int V, int k0, int k1, float u) {
+  // p(v) ~ (1/V + w_t1 (d(v,k1) - 1/V)) (1/V + w_0t (d(v,k0) - 1/V)): only 4 distinct values
+  const float a0 = invV - w_t1 * invV, a1 = a0 + w_t1;      // factor 1 off/on
+  const float b0 = invV - w_0t * invV, b1 = b0 + w_0t;      // factor 2 off/on
+  const float base = a0 * b0;
+  float S = base * (float)V;
+  const float e1 = (k1 == k0) ? (a1 * b1 - base) : (a1 * b0 - base);
+  const float e0 = (k1 == k0) ? 0.0f : (a0 * b1 - base);
+  S += e1 + e0;
+  const float thr = u * S;
+  float acc = 0.0f;
+  int cnt = 0;
+  for (int v = 0; v < V; ++v) {
+    acc += base + (v == k1 ? e1 : 0.0f) + (v == k0 ? e0 : 0.0f);
+    cnt += (acc <= thr) ? 1 : 0;
+  }
+  return cnt < V ? cnt : V - 1;
+}
+
+// per-jet time draw t = eps + (1-eps) U  (multimodal_bridge_matching.py:202); its own tiny launch so
+// that the per-particle kernel does not repeat a Philox call (32-bit multiplies are quarter rate)
+__global__ void __launch_bounds__(256)
+draw_time_kernel(int B, float eps, uint64_t seed, uint64_t offset, float* __restrict__ t_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) {
+    uint32_t r[4];
+    philox4(seed, offset, (uint64_t)b, 0x7001u, r);
+    t_out[b] = eps + (1.0f - eps) * u01(r[0]);
+  }
+}
+
 __global__ void __launch_bounds__(256)
 bridge_sample_rng_kernel(int P, int N, int Dc, int V, float eps, const float* __restrict__ x1,
                          const int64_t* __restrict__ k1, int bridge_kind, float sigma,
@@ -79,12 +133,11 @@ bridge_sample_rng_kernel(int P, int N, int Dc, int V, float eps, const float* __
                          float* __restrict__ t_out, float* __restrict__ x0_out,
                          int64_t* __restrict__ k0_out, float* __restrict__ xt,
                          int64_t* __restrict__ kt) {
+  const float invV = 1.0f / (float)V;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
     int b = p / N;
     uint32_t r[4];
-    philox4(seed, offset, (uint64_t)b, 0x7001u, r);           // per-jet stream
-    float t = eps + (1.0f - eps) * u01(r[0]);
-    if (p - b * N == 0) t_out[b] = t;
+    const float t = t_out[b];                                 // drawn by draw_time_kernel
     philox4(seed, offset, (uint64_t)p, 1u, r);                // per-particle stream, call 1
     float uk = u01(r[0]);
     int k0v = (int)(r[1] % (uint32_t)V);
@@ -92,26 +145,108 @@ bridge_sample_rng_kernel(int P, int N, int Dc, int V, float eps, const float* __
       float std = bridge_std(bridge_kind, sigma, t);
       float omt = 1.0f - t;
       const int64_t base = (int64_t)p * Dc;
-      for (int d0 = 0; d0 < Dc; d0 += 2) {
-        uint32_t q[4];
-        philox4(seed, offset, (uint64_t)p, 2u + (uint32_t)(d0 >> 1), q);
-        float a0, a1, z0, z1;
-        box_muller(q[0], q[1], a0, a1);                        // source x0
-        box_muller(q[2], q[3], z0, z1);                        // regulariser z
-        float s0 = a0;
+      // r[2], r[3] of call 1 feed the first Box-Muller pair; further pairs take their own call
+      float a0, a1, z0, z1;
+      box_muller_fast(r[2], r[3], a0, a1);                    // source x0[0], x0[1]
+      uint32_t q[4];
+      philox4(seed, offset, (uint64_t)p, 2u, q);
+      box_muller_fast(q[0], q[1], z0, z1);                    // z[0], z[1]
+      float s2 = 0.0f, z2 = 0.0f;
+      if (Dc > 2) box_muller_fast(q[2], q[3], s2, z2);         // x0[2], z[2]
+      x0_out[base] = a0;
+      xt[base] = (t * x1[base] + omt * a0) + std * z0;
+      if (Dc > 1) { x0_out[base + 1] = a1; xt[base + 1] = (t * x1[base + 1] + omt * a1) + std * z1; }
+      if (Dc > 2) { x0_out[base + 2] = s2; xt[base + 2] = (t * x1[base + 2] + omt * s2) + std * z2; }
+      for (int d0 = 3; d0 < Dc; d0 += 2) {
+        uint32_t g[4];
+        philox4(seed, offset, (uint64_t)p, 3u + (uint32_t)(d0 >> 1), g);
+        float s0, s1, y0, y1;
+        box_muller_fast(g[0], g[1], s0, s1);
+        box_muller_fast(g[2], g[3], y0, y1);
         x0_out[base + d0] = s0;
-        xt[base + d0] = (t * x1[base + d0] + omt * s0) + std * z0;
-        if (d0 + 1 < Dc) {
-          float s1 = a1;
-          x0_out[base + d0 + 1] = s1;
-          xt[base + d0 + 1] = (t * x1[base + d0 + 1] + omt * s1) + std * z1;
-        }
+        xt[base + d0] = (t * x1[base + d0] + omt * s0) + std * y0;
+        if (d0 + 1 < Dc) { x0_out[base + d0 + 1] = s1; xt[base + d0 + 1] = (t * x1[base + d0 + 1] + omt * s1) + std * y1; }
       }
     }
     if (k1 != nullptr) {
-      TelegraphW w = telegraph_w(thermo_kind, c, t, V);
+      const float w_t1 = thermo_w_fast(thermo_kind, c, t, 1.0f);
+      const float w_0t = thermo_w_fast(thermo_kind, c, 0.0f, t);
       if (k0_out != nullptr) k0_out[p] = k0v;
-      kt[p] = (int64_t)telegraph_draw(w, V, k0v, (int)k1[p], uk);
+      kt[p] = (int64_t)telegraph_draw_fast(w_t1, w_0t, invV, V, k0v, (int)k1[p], uk);
+    }
+  }
+}
+
+// Dc == 3 fast form: one lane owns FOUR consecutive particles = 12 contiguous floats, so x1 is read
+// and x_t / x0 are written as three dwordx4 per lane (a 12-byte particle stride with dword
+// accesses leaves two thirds of every wave request unused), and k as two 16-byte accesses.
+__global__ void __launch_bounds__(256)
+bridge_sample_rng4_kernel(int P4, int N, int V, const float* __restrict__ x1, const int64_t* __restrict__ k1,
+                          int bridge_kind, float sigma, int thermo_kind, float c, uint64_t seed, uint64_t offset,
+                          const float* __restrict__ t_in, float* __restrict__ x0_out, int64_t* __restrict__ k0_out,
+                          float* __restrict__ xt, int64_t* __restrict__ kt) {
+  const float invV = 1.0f / (float)V;
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < P4; g += gridDim.x * blockDim.x) {
+    const int p0 = g * 4;
+    float xs[12], x0v[12], xtv[12];
+    long long k1v[4], k0v[4], ktv[4];
+    if (x1 != nullptr) {
+      const float4* src = reinterpret_cast<const float4*>(x1 + (int64_t)p0 * 3);
+      const float4 a = src[0], b = src[1], d = src[2];
+      xs[0] = a.x; xs[1] = a.y; xs[2] = a.z; xs[3] = a.w; xs[4] = b.x; xs[5] = b.y; xs[6] = b.z; xs[7] = b.w;
+      xs[8] = d.x; xs[9] = d.y; xs[10] = d.z; xs[11] = d.w;
+    }
+    if (k1 != nullptr) {
+      const longlong2* ks = reinterpret_cast<const longlong2*>(k1 + p0);
+      const longlong2 a = ks[0], b = ks[1];
+      k1v[0] = a.x; k1v[1] = a.y; k1v[2] = b.x; k1v[3] = b.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = p0 + j;
+      const float t = t_in[p / N];
+      uint32_t r[4];
+      philox4<7>(seed, offset, (uint64_t)p, 1u, r);
+      const float uk = u01(r[0]);
+      const int k0i = (int)(r[1] % (uint32_t)V);
+      if (x1 != nullptr) {
+        const float std = bridge_std(bridge_kind, sigma, t), omt = 1.0f - t;
+        float a0, a1, z0, z1, s2, z2;
+        box_muller_fast(r[2], r[3], a0, a1);
+        uint32_t q[4];
+        philox4<7>(seed, offset, (uint64_t)p, 2u, q);
+        box_muller_fast(q[0], q[1], z0, z1);
+        box_muller_fast(q[2], q[3], s2, z2);
+        x0v[3 * j] = a0; x0v[3 * j + 1] = a1; x0v[3 * j + 2] = s2;
+        xtv[3 * j] = (t * xs[3 * j] + omt * a0) + std * z0;
+        xtv[3 * j + 1] = (t * xs[3 * j + 1] + omt * a1) + std * z1;
+        xtv[3 * j + 2] = (t * xs[3 * j + 2] + omt * s2) + std * z2;
+      }
+      if (k1 != nullptr) {
+        const float w_t1 = thermo_w_fast(thermo_kind, c, t, 1.0f);
+        const float w_0t = thermo_w_fast(thermo_kind, c, 0.0f, t);
+        k0v[j] = k0i;
+        ktv[j] = telegraph_draw_fast(w_t1, w_0t, invV, V, k0i, (int)k1v[j], uk);
+      }
+    }
+    if (x1 != nullptr) {
+      float4* o0 = reinterpret_cast<float4*>(x0_out + (int64_t)p0 * 3);
+      float4* o1 = reinterpret_cast<float4*>(xt + (int64_t)p0 * 3);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        o0[q] = make_float4(x0v[4 * q], x0v[4 * q + 1], x0v[4 * q + 2], x0v[4 * q + 3]);
+        o1[q] = make_float4(xtv[4 * q], xtv[4 * q + 1], xtv[4 * q + 2], xtv[4 * q + 3]);
+      }
+    }
+    if (k1 != nullptr) {
+      longlong2* o = reinterpret_cast<longlong2*>(kt + p0);
+      o[0] = make_longlong2(ktv[0], ktv[1]);
+      o[1] = make_longlong2(ktv[2], ktv[3]);
+      if (k0_out != nullptr) {
+        longlong2* o2 = reinterpret_cast<longlong2*>(k0_out + p0);
+        o2[0] = make_longlong2(k0v[0], k0v[1]);
+        o2[1] = make_longlong2(k0v[2], k0v[3]);
+      }
     }
   }
 }
@@ -186,9 +321,19 @@ extern "C" int mmb_bridge_sample_rng(int B, int N, int Dc, int V, float eps, con
   MMB_REQUIRE(bridge_kind == 0 || bridge_kind == 1, "mmb_bridge_sample_rng: bad bridge");
   int P = B * N;
   float c = (float)(-(double)V * (double)gamma);
-  hipLaunchKernelGGL(bridge_sample_rng_kernel, dim3(stream_grid(P, 256)), dim3(256), 0, as_stream(stream), P,
-                     N, Dc, V, eps, x1, k1, bridge_kind, sigma, thermo_kind, c, seed, offset, t_out, x0_out,
-                     k0_out, xt, kt);
+  hipLaunchKernelGGL(draw_time_kernel, dim3((B + 255) / 256), dim3(256), 0, as_stream(stream), B, eps, seed, offset,
+                     t_out);
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const bool fast4 = (P % 4 == 0) && (!x1 || (Dc == 3 && al16(x1) && al16(x0_out) && al16(xt))) &&
+                     (!k1 || (al16(k1) && al16(kt) && (!k0_out || al16(k0_out))));
+  if (fast4)
+    hipLaunchKernelGGL(bridge_sample_rng4_kernel, dim3(stream_grid(P / 4, 256)), dim3(256), 0, as_stream(stream),
+                       P / 4, N, V, x1, k1, bridge_kind, sigma, thermo_kind, c, seed, offset, t_out, x0_out, k0_out,
+                       xt, kt);
+  else
+    hipLaunchKernelGGL(bridge_sample_rng_kernel, dim3(stream_grid(P, 256)), dim3(256), 0, as_stream(stream), P,
+                       N, Dc, V, eps, x1, k1, bridge_kind, sigma, thermo_kind, c, seed, offset, t_out, x0_out,
+                       k0_out, xt, kt);
   return check_launch("mmb_bridge_sample_rng");
 }
 

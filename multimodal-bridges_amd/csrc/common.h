@@ -57,14 +57,17 @@ __host__ __device__ inline void philox_round(uint32_t* c, const uint32_t* k) {
   c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
 
-// 4 x 32 random bits for (seed, offset, index, lane-of-call)
+// 4 x 32 random bits for (seed, offset, index, lane-of-call).  ROUNDS = 10 is the standard
+// Philox4x32-10; 7 is the smallest Crush-resistant variant (Salmon et al., SC'11) and is used
+// where the 32-bit multiplies (quarter rate on CDNA) would make an HBM-bound kernel ALU-bound.
+template <int ROUNDS = 10>
 __host__ __device__ inline void philox4(uint64_t seed, uint64_t offset, uint64_t index, uint32_t sub,
                                         uint32_t out[4]) {
   uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), (uint32_t)offset,
                    (uint32_t)(offset >> 32) ^ (sub * 0x9E3779B9u)};
   uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < ROUNDS; ++r) {
     philox_round(c, k);
     k[0] += 0x9E3779B9u;
     k[1] += 0xBB67AE85u;

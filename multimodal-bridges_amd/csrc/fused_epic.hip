@@ -16,6 +16,14 @@
 // than the concatenated formulation, same result up to fp32 summation order).
 // Masked mean/sum pooling is a DPP reduction over the 32 particle lanes + an LDS combine of the 4
 // waves.  The per-jet MLPs (M = 1 row) are VALU matvecs over transposed weights.
+//
+// Occupancy.  The per-jet chain pool -> fc_glob1 -> fc_glob2 -> d-vector is serial and latency
+// bound (L2 weight fetches + barriers), and nothing of the SAME jet can overlap it.  So the kernel
+// is built to run TWO workgroups (two jets) per CU: the register budget is held to 256 per wave
+// (unified VGPR+AGPR file, 512 per SIMD lane) by parking the fused encoder's skip/input tiles
+// (cat[h1,h2], read once per layer and by the heads) in LDS -- 64 KiB per jet, each lane reading back
+// only what it wrote (no barrier, conflict-free b128) -- and by folding the residual into the
+// accumulator's initial value.  One jet's matvec latency then hides under the other jet's MFMAs.
 #include "common.h"
 #include <utility>
 
@@ -69,34 +77,50 @@ struct alignas(16) Lds {
   float gcur[64], gskip[64], gnew[64], gcat[64];
   float pooled[2 * 128 + 128];
   float partial[4 * 128];
-  float scratch[FE_THREADS];
+  float scratch[4 * FE_THREADS];
   float gh[128];
   float cvec[128], dvec[128];
   float cw[32 * 4], cb[32];       // continuous embedding weight [Ec][Dc<=4], bias
-  float table[32 * 32];           // discrete embedding table [V<=32][Ed<=32]
+  float table[8 * 32];            // discrete embedding table [V<=8][Ed<=32]
   float cnt;
   int red[4];
 };
 
-// out[o] = act( sum_k WT[k*O+o] * v[k] + bias[o] ) + add[o]   -- v/out/add live in LDS
+// out[o] = act( sum_k WT[k*O+o] * v[k] + bias[o] ) + add[o]   -- v/out/add live in LDS.
+// Each thread owns FOUR consecutive outputs (one dwordx4 per k) and every P-th k; up to 12 loads
+// are in flight per thread so the L2 latency of the weight stream is paid ~K/(12 P) times, not K/P.
+// O must be a multiple of 4 and O/4 <= 256.
 template <int ACT>
 __device__ void matvec(const float* __restrict__ WT, const float* __restrict__ bias, const float* v, int K, int O,
                        float* out, const float* add, float* scratch, int tid) {
-  int P = FE_THREADS / O;
-  if (P > 16) P = 16;
-  const int o = tid % O, part = tid / O;
+  const int O4 = O >> 2;
+  int P = FE_THREADS / O4;                         // k-partitions
+  if (P > 64) P = 64;
+  const int o4 = tid % O4, part = tid / O4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (part < P) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float4* w4 = reinterpret_cast<const float4*>(WT) + o4;
     int k = part;
-    for (; k + 3 * P < K; k += 4 * P) {
-      s0 += WT[(int64_t)k * O + o] * v[k];
-      s1 += WT[(int64_t)(k + P) * O + o] * v[k + P];
-      s2 += WT[(int64_t)(k + 2 * P) * O + o] * v[k + 2 * P];
-      s3 += WT[(int64_t)(k + 3 * P) * O + o] * v[k + 3 * P];
+    constexpr int UN = 12;
+    for (; k + (UN - 1) * P < K; k += UN * P) {
+      float4 w[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) w[u] = w4[(int64_t)(k + u * P) * O4];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const float vv = v[k + u * P];
+        s.x += w[u].x * vv; s.y += w[u].y * vv; s.z += w[u].z * vv; s.w += w[u].w * vv;
+      }
     }
-    for (; k < K; k += P) s0 += WT[(int64_t)k * O + o] * v[k];
-    scratch[part * O + o] = (s0 + s1) + (s2 + s3);
+    for (; k < K; k += P) {
+      const float4 w = w4[(int64_t)k * O4];
+      const float vv = v[k];
+      s.x += w.x * vv; s.y += w.y * vv; s.z += w.z * vv; s.w += w.w * vv;
+    }
   }
+  // combine the P partitions: partitions live in different lanes/waves -> LDS, [part][O]
+  // (scratch holds P*O <= 1024 floats)
+  if (part < P) *reinterpret_cast<float4*>(&scratch[part * O + 4 * o4]) = s;
   __syncthreads();
   if (tid < O) {
     float t = bias ? bias[tid] : 0.0f;
@@ -108,28 +132,45 @@ __device__ void matvec(const float* __restrict__ WT, const float* __restrict__ b
   __syncthreads();
 }
 
-// acc[ot] += W_x (tile rows ot) * X^T, X^T tiles delivered by `tile(IF<ft>)`.
+// A lane's 16 values of tile t parked in / fetched from LDS: slot (t,q) holds one float4 per thread.
+__device__ __forceinline__ void park_tile(float4* S, int t, const f32x16& v, int tid) {
+  ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
+    S[(t * 4 + q) * FE_THREADS + tid] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]); });
+}
+__device__ __forceinline__ f32x16 fetch_tile(const float4* S, int t, int tid) {
+  f32x16 v;
+  ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
+    const float4 a = S[(t * 4 + q) * FE_THREADS + tid];
+    v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w; });
+  return v;
+}
+
+// acc[ot] += W_x (tile rows ot) * X^T, X^T tiles delivered by `tile(IF<ft>)` (a reference to
+// registers, or a value fetched from LDS).
 template <int KT, int OT, typename TileFn>
 __device__ __forceinline__ void mma_x(f32x16 (&acc)[OT], TileFn&& tile, const float* __restrict__ Wp, int lane) {
   const float4* w4 = reinterpret_cast<const float4*>(Wp) + lane;
   float4 a_cur[OT], a_nxt[OT];
   ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; a_cur[ot] = w4[ot * 64]; });
-  ffor<KT * 4>([&](auto gc) {
-    constexpr int g = decltype(gc)::v;          // group = (ft, q): four k-steps r = 4q..4q+3
-    constexpr int ft = g / 4, q = g % 4;
-    if constexpr (g + 1 < KT * 4)
-      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; a_nxt[ot] = w4[((g + 1) * OT + ot) * 64]; });
-    const f32x16& xt = tile(IF<ft>{});
-    ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-      acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ot].x, xt[4 * q + 0], acc[ot], 0, 0, 0); });
-    ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-      acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ot].y, xt[4 * q + 1], acc[ot], 0, 0, 0); });
-    ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-      acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ot].z, xt[4 * q + 2], acc[ot], 0, 0, 0); });
-    ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-      acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ot].w, xt[4 * q + 3], acc[ot], 0, 0, 0); });
-    if constexpr (g + 1 < KT * 4)
-      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; a_cur[ot] = a_nxt[ot]; });
+  ffor<KT>([&](auto fc) {
+    constexpr int ft = decltype(fc)::v;
+    decltype(auto) xt = tile(IF<ft>{});
+    ffor<4>([&](auto qc) {
+      constexpr int q = decltype(qc)::v;          // group = (ft, q): four k-steps r = 4q..4q+3
+      constexpr int g = ft * 4 + q;
+      if constexpr (g + 1 < KT * 4)
+        ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; a_nxt[ot] = w4[((g + 1) * OT + ot) * 64]; });
+      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ot].x, xt[4 * q + 0], acc[ot], 0, 0, 0); });
+      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ot].y, xt[4 * q + 1], acc[ot], 0, 0, 0); });
+      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ot].z, xt[4 * q + 2], acc[ot], 0, 0, 0); });
+      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ot].w, xt[4 * q + 3], acc[ot], 0, 0, 0); });
+      if constexpr (g + 1 < KT * 4)
+        ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; a_cur[ot] = a_nxt[ot]; });
+    });
   });
 }
 
@@ -182,16 +223,30 @@ __device__ __forceinline__ void build_pooled(int H, int T, const float* tail, Ld
   __syncthreads();
 }
 
+// time vector c = W_t temb of a layer: taken from the per-grid-point table when the caller
+// precomputed it (generation: t is the same for every jet), else a matvec into L.cvec.
+__device__ __forceinline__ const float* time_vec(const float* ctab, int& ci, const float* WtT, int ET, int O, Lds& L,
+                                                 int tid) {
+  if (ctab != nullptr) {
+    const float* c = ctab + (int64_t)ci * 128;
+    ++ci;
+    return c;
+  }
+  matvec<MMB_ACT_NONE>(WtT, nullptr, L.temb, ET, O, L.cvec, nullptr, L.scratch, tid);
+  return L.cvec;
+}
+
 // ------------------------------------------------------------------ one EPiC encoder ----
 // x: HT tiles (in/out), skip: HT tiles.  Global vector in L.gcur.  `li` walks the descriptors.
 template <int HT, int ET>
 struct Epic {
   static constexpr int H = 32 * HT;
 
-  // EPiCLayer (epic.py:187-208) + the encoder-level skip add (:89-90)
-  static __device__ __forceinline__ void layer(f32x16 (&x)[HT], const f32x16 (&skip)[HT], bool use_skip, int G,
+  // EPiCLayer (epic.py:187-208) + the encoder-level skip add (:89-90).  skipf(IF<t>) yields skip tile t.
+  template <typename SkipFn>
+  static __device__ __forceinline__ void layer(f32x16 (&x)[HT], SkipFn&& skipf, bool use_skip, int G,
                                                const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
-                                               float m, int tid) {
+                                               float m, int tid, const float* ctab, int& ci) {
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const LDesc g1 = D[li], g2 = D[li + 1], l1 = D[li + 2], l2 = D[li + 3];
     li += 4;
@@ -199,46 +254,52 @@ struct Epic {
     build_pooled(H, G, L.gcur, L, tid);
     matvec<MMB_ACT_LRELU>(P + g1.wt, P + g1.b, L.pooled, 2 * H + G, H, L.gh, nullptr, L.scratch, tid);
     matvec<MMB_ACT_NONE>(P + g2.wt, P + g2.b, L.gh, H, G, L.gnew, L.gcur, L.scratch, tid);   // g' = g + fc_glob2(.)
-    matvec<MMB_ACT_NONE>(P + l1.wt, nullptr, L.temb, ET, H, L.cvec, nullptr, L.scratch, tid);
+    const float* cv = time_vec(ctab, ci, P + l1.wt, ET, H, L, tid);
     matvec<MMB_ACT_NONE>(P + l1.wg, P + l1.b, L.gnew, G, H, L.dvec, nullptr, L.scratch, tid);
     if (tid < G) L.gcur[tid] = lrelu_f(L.gnew[tid]) + (use_skip ? L.gskip[tid] : 0.0f);
     f32x16 lh[HT];
-    acc_init<HT>(lh, m, L.cvec, L.dvec, half);
+    acc_init<HT>(lh, m, cv, L.dvec, half);
     mma_x<HT, HT>(lh, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, P + l1.wx, lane);
     act_tiles<HT, MMB_ACT_LRELU>(lh);
-    f32x16 a2[HT];
-    acc_init<HT>(a2, 0.0f, nullptr, P + l2.b, half);
-    mma_x<HT, HT>(a2, [&](auto fc) -> const f32x16& { return lh[decltype(fc)::v]; }, P + l2.wx, lane);
+    // x <- (x + b2) + W2 lh : the residual rides in the accumulator, x's registers ARE the accumulator
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
-      ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v;
-        const float v = lrelu_f(x[t][r] + a2[t][r]);
-        x[t][r] = use_skip ? v + skip[t][r] : v; }); });
+      ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
+        const float4 bv = *reinterpret_cast<const float4*>(P + l2.b + 32 * t + 8 * q + 4 * half);
+        x[t][4 * q + 0] += bv.x; x[t][4 * q + 1] += bv.y; x[t][4 * q + 2] += bv.z; x[t][4 * q + 3] += bv.w; }); });
+    mma_x<HT, HT>(x, [&](auto fc) -> const f32x16& { return lh[decltype(fc)::v]; }, P + l2.wx, lane);
+    ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+      if (use_skip) {
+        const f32x16 sk = skipf(IF<t>{});
+        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; x[t][r] = lrelu_f(x[t][r]) + sk[r]; });
+      } else {
+        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; x[t][r] = lrelu_f(x[t][r]); });
+      } });
     __syncthreads();                                   // gcur settled before the next pooled build
   }
 
   // output layer: wn Linear on cat[t, x, g] (epic.py:93-96)
   static __device__ __forceinline__ void output(f32x16 (&out)[HT], const f32x16 (&x)[HT], int G,
                                                 const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
-                                                float m, int tid) {
+                                                float m, int tid, const float* ctab, int& ci) {
     const int lane = tid & 63, half = lane >> 5;
     const LDesc o = D[li];
     li += 1;
-    matvec<MMB_ACT_NONE>(P + o.wt, nullptr, L.temb, ET, H, L.cvec, nullptr, L.scratch, tid);
+    const float* cv = time_vec(ctab, ci, P + o.wt, ET, H, L, tid);
     matvec<MMB_ACT_NONE>(P + o.wg, P + o.b, L.gcur, G, H, L.dvec, nullptr, L.scratch, tid);
-    acc_init<HT>(out, m, L.cvec, L.dvec, half);
+    acc_init<HT>(out, m, cv, L.dvec, half);
     mma_x<HT, HT>(out, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, P + o.wx, lane);
   }
 
   // EPiCProjection (epic.py:145-159) from ONE padded input tile
   static __device__ __forceinline__ void project(f32x16 (&x)[HT], const f32x16& xin, int G,
                                                  const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
-                                                 float m, int tid) {
+                                                 float m, int tid, const float* ctab, int& ci) {
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const LDesc p0 = D[li], p2 = D[li + 1], q0 = D[li + 2], q2 = D[li + 3];
     li += 4;
-    matvec<MMB_ACT_NONE>(P + p0.wt, nullptr, L.temb, ET, H, L.cvec, nullptr, L.scratch, tid);
+    const float* cv = time_vec(ctab, ci, P + p0.wt, ET, H, L, tid);
     f32x16 h[HT];
-    acc_init<HT>(h, m, L.cvec, P + p0.b, half);
+    acc_init<HT>(h, m, cv, P + p0.b, half);
     mma_x<1, HT>(h, [&](auto) -> const f32x16& { return xin; }, P + p0.wx, lane);
     act_tiles<HT, MMB_ACT_GELU>(h);
     acc_init<HT>(x, 0.0f, nullptr, P + p2.b, half);
@@ -261,6 +322,7 @@ struct Dims {
 };
 
 struct FusedArgs {
+  const float* ctab;       // generation: (n_c_layers,128) time vectors W_t temb of the CURRENT grid point, or NULL
   const float* P;          // packed parameters
   const LDesc* D;          // layer descriptors
   int nb_branch, nb_fused_exec, use_skip;
@@ -293,26 +355,27 @@ __device__ __forceinline__ void embed_tiles(f32x16& tc, f32x16& td, const float 
 // Whole MultiModalEPiC forward for this jet.  which: 0 continuous head, 1 discrete head, 2 both.
 // hc: tile whose features 0..DC-1 are the drift; hd: tile whose features 0..V-1 are the logits.
 template <class DM>
-__device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, const float (&xp)[4], int kp, float m, int which,
-                                            f32x16& hc, f32x16& hd, int tid) {
+__device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* S, const float (&xp)[4], int kp, float m,
+                                            int which, f32x16& hc, f32x16& hd, int tid) {
   constexpr int HBT = DM::HBT, HFT = DM::HFT;
   const int lane = tid & 63, half = lane >> 5;
-  int li = 0;
+  int li = 0, ci = 0;
   f32x16 tc, td;
   embed_tiles<DM>(tc, td, xp, kp, m, L, half);
-  f32x16 skip[HFT];                 // = cat[h1, h2]: fused-encoder input AND its skip connection
+  // S (LDS, HFT tiles) = cat[h1, h2]: fused-encoder input, its skip connection AND the heads' input
   // ---- two branch encoders (multimodal_epic.py:173-175)
   ffor<2>([&](auto bc) {
     constexpr int br = decltype(bc)::v;
     f32x16 x[HBT], sk[HBT], out[HBT];
-    Epic<HBT, DM::ET>::project(x, br == 0 ? tc : td, DM::GB, A.P, A.D, li, L, m, tid);
+    Epic<HBT, DM::ET>::project(x, br == 0 ? tc : td, DM::GB, A.P, A.D, li, L, m, tid, A.ctab, ci);
     if (tid < DM::GB) L.gskip[tid] = L.gcur[tid];
     ffor<HBT>([&](auto t) { sk[decltype(t)::v] = x[decltype(t)::v]; });
     __syncthreads();
     for (int i = 0; i < A.nb_branch; ++i)
-      Epic<HBT, DM::ET>::layer(x, sk, A.use_skip != 0, DM::GB, A.P, A.D, li, L, m, tid);
-    Epic<HBT, DM::ET>::output(out, x, DM::GB, A.P, A.D, li, L, m, tid);
-    ffor<HBT>([&](auto t) { skip[br * HBT + decltype(t)::v] = out[decltype(t)::v]; });
+      Epic<HBT, DM::ET>::layer(x, [&](auto t) -> const f32x16& { return sk[decltype(t)::v]; }, A.use_skip != 0,
+                               DM::GB, A.P, A.D, li, L, m, tid, A.ctab, ci);
+    Epic<HBT, DM::ET>::output(out, x, DM::GB, A.P, A.D, li, L, m, tid, A.ctab, ci);
+    ffor<HBT>([&](auto t) { park_tile(S, br * HBT + decltype(t)::v, out[decltype(t)::v], tid); });
     if (tid < DM::GB) L.gcat[br * DM::GB + tid] = L.gcur[tid];
     __syncthreads();
   });
@@ -320,19 +383,22 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, const fl
   if (tid < DM::GF) { L.gcur[tid] = L.gcat[tid]; L.gskip[tid] = L.gcat[tid]; }
   __syncthreads();
   f32x16 x[HFT], f[HFT];
-  ffor<HFT>([&](auto t) { x[decltype(t)::v] = skip[decltype(t)::v]; });
+  ffor<HFT>([&](auto t) { x[decltype(t)::v] = fetch_tile(S, decltype(t)::v, tid); });
   for (int i = 0; i < A.nb_fused_exec; ++i)
-    Epic<HFT, DM::ET>::layer(x, skip, A.use_skip != 0, DM::GF, A.P, A.D, li, L, m, tid);
-  Epic<HFT, DM::ET>::output(f, x, DM::GF, A.P, A.D, li, L, m, tid);
+    Epic<HFT, DM::ET>::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, decltype(t)::v, tid); }, A.use_skip != 0,
+                             DM::GF, A.P, A.D, li, L, m, tid, A.ctab, ci);
+  Epic<HFT, DM::ET>::output(f, x, DM::GF, A.P, A.D, li, L, m, tid, A.ctab, ci);
   // ---- heads (multimodal_epic.py:187-189): cat[t, f_i, h_i] -> GELU -> out
   const LDesc c0 = A.D[li], c2 = A.D[li + 1], d0 = A.D[li + 2], d2 = A.D[li + 3];
+  const int ci_heads = ci;                               // table slots: [.. , continuous head, discrete head]
   if (which != 1) {
-    matvec<MMB_ACT_NONE>(A.P + c0.wt, nullptr, L.temb, DM::ET, DM::HB, L.cvec, nullptr, L.scratch, tid);
+    ci = ci_heads;
+    const float* cv = time_vec(A.ctab, ci, A.P + c0.wt, DM::ET, DM::HB, L, tid);
     f32x16 h[HBT];
-    acc_init<HBT>(h, m, L.cvec, A.P + c0.b, half);
-    mma_x<HFT, HBT>(h, [&](auto fc) -> const f32x16& {
+    acc_init<HBT>(h, m, cv, A.P + c0.b, half);
+    mma_x<HFT, HBT>(h, [&](auto fc) -> f32x16 {
       constexpr int t = decltype(fc)::v;
-      if constexpr (t < HBT) return f[t]; else return skip[t - HBT]; }, A.P + c0.wx, lane);
+      if constexpr (t < HBT) return f[t]; else return fetch_tile(S, t - HBT, tid); }, A.P + c0.wx, lane);
     act_tiles<HBT, MMB_ACT_GELU>(h);
     f32x16 o[1];
     acc_init<1>(o, 0.0f, nullptr, A.P + c2.b, half);
@@ -340,12 +406,13 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, const fl
     hc = o[0];
   }
   if (which != 0) {
-    matvec<MMB_ACT_NONE>(A.P + d0.wt, nullptr, L.temb, DM::ET, DM::HB, L.cvec, nullptr, L.scratch, tid);
+    ci = ci_heads + 1;
+    const float* cv = time_vec(A.ctab, ci, A.P + d0.wt, DM::ET, DM::HB, L, tid);
     f32x16 h[HBT];
-    acc_init<HBT>(h, m, L.cvec, A.P + d0.b, half);
-    mma_x<HFT, HBT>(h, [&](auto fc) -> const f32x16& {
+    acc_init<HBT>(h, m, cv, A.P + d0.b, half);
+    mma_x<HFT, HBT>(h, [&](auto fc) -> f32x16 {
       constexpr int t = decltype(fc)::v;
-      if constexpr (t < HBT) return f[HBT + t]; else return skip[t]; }, A.P + d0.wx, lane);
+      if constexpr (t < HBT) return f[HBT + t]; else return fetch_tile(S, t, tid); }, A.P + d0.wx, lane);
     act_tiles<HBT, MMB_ACT_GELU>(h);
     f32x16 o[1];
     acc_init<1>(o, 0.0f, nullptr, A.P + d2.b, half);
@@ -385,11 +452,12 @@ __device__ __forceinline__ void gather_logits(const f32x16& hd, float (&lg)[DM::
 
 // ---- single forward: heads to HBM (validation / parity / training-forward of eval mode) ----
 template <class DM>
-__global__ void __launch_bounds__(FE_THREADS, 1)
+__global__ void __launch_bounds__(FE_THREADS, 2)
 fused_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64_t* __restrict__ k,
                      const float* __restrict__ temb, int64_t temb_stride, int which, float* __restrict__ head_c,
                      float* __restrict__ head_d) {
   __shared__ Lds L;
+  __shared__ float4 S[DM::HFT * 4 * FE_THREADS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   load_constants<DM>(A, L, tid);
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
@@ -406,7 +474,7 @@ fused_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64_t* __
     const int kp = valid ? (int)k[gp] : 0;
     __syncthreads();
     f32x16 hc, hd;
-    forward_jet<DM>(A, L, xp, kp, m, which, hc, hd, tid);
+    forward_jet<DM>(A, L, S, xp, kp, m, which, hc, hd, tid);
     if (valid && which != 1 && half == 0) {
 #pragma unroll
       for (int d = 0; d < DM::DC; ++d) head_c[gp * DM::DC + d] = hc[d];       // features 0..2 = regs 0..2, half 0
@@ -427,6 +495,8 @@ struct GenArgs {
   int steps;
   const float* times;        // (steps) grid points (host linspace, fp32)
   const float* temb_steps;   // (steps, ET) time embedding per grid point (identical for every jet)
+  const float* ctab_steps;   // (steps, n_ctab, 128) precomputed W_t temb of every time-consuming layer
+  int n_ctab;
   float dt;
   int thermo_kind;
   float thermo_c;            // fp32(-V*gamma)
@@ -437,9 +507,10 @@ struct GenArgs {
 __device__ __forceinline__ float thermo_w_f(int kind, float c, float t0, float t1) { return thermo_w(kind, c, t0, t1); }
 
 template <class DM>
-__global__ void __launch_bounds__(FE_THREADS, 1)
+__global__ void __launch_bounds__(FE_THREADS, 2)
 fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* __restrict__ k) {
   __shared__ Lds L;
+  __shared__ float4 S[DM::HFT * 4 * FE_THREADS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   constexpr int V = DM::V;
   load_constants<DM>(A, L, tid);
@@ -458,10 +529,11 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
       __syncthreads();
       if (tid < DM::ET) L.temb[tid] = Gn.temb_steps[(int64_t)s * DM::ET + tid];
       __syncthreads();
+      A.ctab = Gn.ctab_steps ? Gn.ctab_steps + (int64_t)s * Gn.n_ctab * 128 : nullptr;
       const float tt = Gn.times[s];
       f32x16 hc, hd;
       // Euler step on the drift head (solvers.py:21-25); padded slots move too (K3)
-      forward_jet<DM>(A, L, xp, kp, m, 0, hc, hd, tid);
+      forward_jet<DM>(A, L, S, xp, kp, m, 0, hc, hd, tid);
       {
         float v[3] = {hc[0], hc[1], hc[2]};
 #pragma unroll
@@ -473,7 +545,7 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
       }
       __syncthreads();
       // tau-leap on the logits head, which sees the UPDATED x at the same t (solvers.py:59-81)
-      forward_jet<DM>(A, L, xp, kp, m, 1, hc, hd, tid);
+      forward_jet<DM>(A, L, S, xp, kp, m, 1, hc, hd, tid);
       float r[V];
       gather_logits<DM>(hd, r, lane);
       {
@@ -561,9 +633,9 @@ extern "C" int mmb_fused_epic_forward(int variant, int B, int N, const float* pa
   MMB_REQUIRE(which >= 0 && which <= 2, "mmb_fused_epic_forward: which=%d", which);
   if (which != 1) MMB_REQUIRE(head_c, "mmb_fused_epic_forward: head_c is NULL");
   if (which != 0) MMB_REQUIRE(head_d, "mmb_fused_epic_forward: head_d is NULL");
-  FusedArgs A{packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
+  FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
               off_table, B, N, maskf, counts};
-  const int grid = B < 2048 ? B : 2048;
+  const int grid = B < 4096 ? B : 4096;
   if (variant == 0)
     hipLaunchKernelGGL(fused_forward_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k, temb,
                        temb_stride, which, head_c, head_d);
@@ -576,7 +648,8 @@ extern "C" int mmb_fused_epic_forward(int variant, int B, int N, const float* pa
 extern "C" int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, const int32_t* desc,
                                        int nb_branch, int nb_fused_exec, int use_skip, int off_cw, int off_cb,
                                        int off_table, const float* maskf, const int32_t* counts, float* x, int64_t* k,
-                                       int steps, const float* times, const float* temb_steps, float dt,
+                                       int steps, const float* times, const float* temb_steps,
+                                       const float* ctab_steps, int n_ctab, float dt,
                                        int thermo_kind, float gamma, const float* delta_n, uint64_t seed,
                                        uint64_t offset, void* stream) {
   int rc = check_fused("mmb_fused_epic_generate", B, N, packed, desc, maskf, counts);
@@ -584,10 +657,10 @@ extern "C" int mmb_fused_epic_generate(int variant, int B, int N, const float* p
   MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_epic_generate: unknown variant %d", variant);
   MMB_REQUIRE(x && k && times && temb_steps && steps > 0, "mmb_fused_epic_generate: NULL state / steps");
   MMB_REQUIRE(thermo_kind >= 0 && thermo_kind <= 4, "mmb_fused_epic_generate: bad thermostat");
-  FusedArgs A{packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
+  FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
               off_table, B, N, maskf, counts};
-  GenArgs Gn{steps, times, temb_steps, dt, thermo_kind, (float)(-(double)8 * (double)gamma), delta_n, seed, offset};
-  const int grid = B < 2048 ? B : 2048;
+  GenArgs Gn{steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, (float)(-(double)8 * (double)gamma), delta_n, seed, offset};
+  const int grid = B < 4096 ? B : 4096;
   if (variant == 0)
     hipLaunchKernelGGL(fused_generate_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k);
   else

@@ -17,6 +17,7 @@ __device__ inline float drift_value2(int bridge_kind, float t, float xt, float x
 
 constexpr int LOSS_MAXV = 32;
 
+template <bool V8>
 __global__ void __launch_bounds__(256)
 loss_kernel(int P, int N, int Dc, int V, const float* __restrict__ head_c, const float* __restrict__ head_d,
             const float* __restrict__ t, const float* __restrict__ xt, const float* __restrict__ x0,
@@ -44,17 +45,39 @@ loss_kernel(int P, int N, int Dc, int V, const float* __restrict__ head_c, const
     if (head_d != nullptr) {
       const float* lp = head_d + (int64_t)p * V;
       const int y = (int)k1[p];
-      float mx = -INFINITY;
-      for (int v = 0; v < V; ++v) mx = fmaxf(mx, lp[v]);
-      float s = 0.0f;
-      for (int v = 0; v < V; ++v) s += expf(lp[v] - mx);
-      const float lse = mx + logf(s);
       const float wy = vocab_freq ? vocab_freq[y] : 1.0f;
-      acc_d += (wy * (lse - lp[y])) * m;
-      if (d_head_d) {
-        float* gp = d_head_d + (int64_t)p * V;
-        const float sc = gd * wy * m;
-        for (int v = 0; v < V; ++v) gp[v] = sc * (expf(lp[v] - lse) - (v == y ? 1.0f : 0.0f));
+      if (V8) {                                   // vocab 8: two float4 loads / stores, one exp per class
+        const float4 a = reinterpret_cast<const float4*>(lp)[0], bq = reinterpret_cast<const float4*>(lp)[1];
+        float l[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+        float mx = l[0];
+#pragma unroll
+        for (int v = 1; v < 8; ++v) mx = fmaxf(mx, l[v]);
+        float e[8], s = 0.0f, ly = 0.0f;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) { e[v] = expf(l[v] - mx); s += e[v]; ly = (v == y) ? l[v] : ly; }
+        const float lse = mx + logf(s);
+        acc_d += (wy * (lse - ly)) * m;
+        if (d_head_d) {
+          const float sc = gd * wy * m, inv = 1.0f / s;
+          float gq[8];
+#pragma unroll
+          for (int v = 0; v < 8; ++v) gq[v] = sc * (e[v] * inv - (v == y ? 1.0f : 0.0f));
+          float4* gp = reinterpret_cast<float4*>(d_head_d + (int64_t)p * 8);
+          gp[0] = make_float4(gq[0], gq[1], gq[2], gq[3]);
+          gp[1] = make_float4(gq[4], gq[5], gq[6], gq[7]);
+        }
+      } else {
+        float mx = -INFINITY;
+        for (int v = 0; v < V; ++v) mx = fmaxf(mx, lp[v]);
+        float s = 0.0f;
+        for (int v = 0; v < V; ++v) s += expf(lp[v] - mx);
+        const float lse = mx + logf(s);
+        acc_d += (wy * (lse - lp[y])) * m;
+        if (d_head_d) {
+          float* gp = d_head_d + (int64_t)p * V;
+          const float sc = gd * wy * m;
+          for (int v = 0; v < V; ++v) gp[v] = sc * (expf(lp[v] - lse) - (v == y ? 1.0f : 0.0f));
+        }
       }
     }
   }
@@ -98,21 +121,30 @@ __global__ void multimode_kernel(const float* losses, const float* s, float w0, 
 }
 
 template <typename MT>
-__global__ void __launch_bounds__(64)
-mask_prepare_kernel(int N, const MT* __restrict__ mask, float* __restrict__ maskf, int32_t* __restrict__ counts,
+__global__ void __launch_bounds__(256)
+mask_prepare_kernel(int B, int N, const MT* __restrict__ mask, float* __restrict__ maskf, int32_t* __restrict__ counts,
                     int32_t* __restrict__ total) {
-  const int b = blockIdx.x;
-  int cnt = 0;
-  for (int n = threadIdx.x; n < N; n += 64) {
-    bool on = mask[(int64_t)b * N + n] != (MT)0;
-    maskf[(int64_t)b * N + n] = on ? 1.0f : 0.0f;
-    cnt += on ? 1 : 0;
-  }
+  // one wave per jet, grid-stride over jets; the batch total costs one atomic per block
+  __shared__ int blk[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int mine = 0;
+  for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
+    int cnt = 0;
+    for (int n = lane; n < N; n += 64) {
+      const bool on = mask[(int64_t)b * N + n] != (MT)0;
+      maskf[(int64_t)b * N + n] = on ? 1.0f : 0.0f;
+      cnt += on ? 1 : 0;
+    }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-  if (threadIdx.x == 0) {
-    counts[b] = cnt;
-    if (total) atomicAdd(total, cnt);
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) counts[b] = cnt;
+    mine += cnt;
+  }
+  if (lane == 0) blk[wave] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0 && total) {
+    const int s = blk[0] + blk[1] + blk[2] + blk[3];
+    if (s) atomicAdd(total, s);
   }
 }
 
@@ -129,11 +161,11 @@ extern "C" int mmb_mask_prepare(int B, int N, const void* mask, int mask_is_i64,
     if (e != hipSuccess) { set_error("mmb_mask_prepare: memset failed: %s", hipGetErrorString(e)); return MMB_ERR_LAUNCH; }
   }
   if (mask_is_i64)
-    hipLaunchKernelGGL(mask_prepare_kernel<int64_t>, dim3(B), dim3(64), 0, as_stream(stream), N,
-                       (const int64_t*)mask, maskf, counts, total);
+    hipLaunchKernelGGL(mask_prepare_kernel<int64_t>, dim3(stream_grid((int64_t)B * 64, 256)), dim3(256), 0,
+                       as_stream(stream), B, N, (const int64_t*)mask, maskf, counts, total);
   else
-    hipLaunchKernelGGL(mask_prepare_kernel<float>, dim3(B), dim3(64), 0, as_stream(stream), N, (const float*)mask,
-                       maskf, counts, total);
+    hipLaunchKernelGGL(mask_prepare_kernel<float>, dim3(stream_grid((int64_t)B * 64, 256)), dim3(256), 0,
+                       as_stream(stream), B, N, (const float*)mask, maskf, counts, total);
   return check_launch("mmb_mask_prepare");
 }
 
@@ -152,8 +184,14 @@ extern "C" int mmb_loss_fwd_bwd(int B, int N, int Dc, int V, const float* head_c
   int P = B * N;
   int grid = (P + 255) / 256;
   if (grid > MMB_LOSS_MAX_BLOCKS) grid = MMB_LOSS_MAX_BLOCKS;
-  hipLaunchKernelGGL(loss_kernel, dim3(grid), dim3(256), 0, as_stream(stream), P, N, Dc, V, head_c, head_d, t, xt,
-                     x0, x1, bridge_kind, k1, maskf, total, vocab_freq, coef, partials, d_head_c, d_head_d);
+  const bool v8 = head_d && V == 8 && ((reinterpret_cast<uintptr_t>(head_d) & 15) == 0) &&
+                  (!d_head_d || (reinterpret_cast<uintptr_t>(d_head_d) & 15) == 0);
+  if (v8)
+    hipLaunchKernelGGL(loss_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), P, N, Dc, V, head_c, head_d, t,
+                       xt, x0, x1, bridge_kind, k1, maskf, total, vocab_freq, coef, partials, d_head_c, d_head_d);
+  else
+    hipLaunchKernelGGL(loss_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), P, N, Dc, V, head_c, head_d,
+                       t, xt, x0, x1, bridge_kind, k1, maskf, total, vocab_freq, coef, partials, d_head_c, d_head_d);
   int rc = check_launch("mmb_loss_fwd_bwd");
   if (rc) return rc;
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), grid, partials, total, losses);

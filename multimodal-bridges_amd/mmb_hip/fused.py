@@ -48,6 +48,7 @@ def eligible(model):
 class _Packer:
     def __init__(self, device):
         self.chunks, self.n, self.desc, self.device = [], 0, [], device
+        self.time_parts = []          # W[:, :Et] of every layer that consumes the time embedding, kernel order
 
     def add(self, t):
         t = t.contiguous().reshape(-1).float()
@@ -79,6 +80,8 @@ class _Packer:
         """columns = [t (n_t) | x (n_x) | g (n_g)]"""
         W = lin.weight()
         wt = self.add(W[:, :n_t].t()) if n_t else -1
+        if n_t:
+            self.time_parts.append(W[:, :n_t])
         wx = self.add(self.pack_x(W[:, n_t:n_t + n_x]))
         wg = self.add(W[:, n_t + n_x:].t()) if n_g else -1
         self.desc.append([wx, wt, wg, self.bias(lin.bias.detach())])
@@ -132,7 +135,18 @@ def pack_model(model):
     desc = torch.tensor(pk.desc, dtype=torch.int32, device=dev).reshape(-1)
     return {"packed": packed, "desc": desc, "variant": variant, "nb_branch": enc.continuous_encoder.num_blocks,
             "nb_fused_exec": fe.num_blocks, "use_skip": int(bool(cfg.encoder.skip_connection)),
-            "off_cw": off_cw, "off_cb": off_cb, "off_table": off_table}
+            "off_cw": off_cw, "off_cb": off_cb, "off_table": off_table, "time_parts": pk.time_parts}
+
+
+def time_vector_table(pack, temb_steps):
+    """(steps, n_ctab, 128): c = W_t temb for every time-consuming layer at every grid point."""
+    from . import ops
+    steps = temb_steps.shape[0]
+    parts = pack["time_parts"]
+    tab = torch.zeros(steps, len(parts), 128, dtype=torch.float32, device=temb_steps.device)
+    for i, Wt in enumerate(parts):
+        ops.linear_cat([(temb_steps, ops.SEG_ROW)], Wt, None, 1, out=tab[:, i, :Wt.shape[0]])
+    return tab
 
 
 def params_version(model):
@@ -152,13 +166,14 @@ def forward(pack, mi, x, k, temb, which, temb_stride=None):
     return hc, hd
 
 
-def generate(pack, mi, x, k, times, temb_steps, dt, thermo_kind, gamma, delta_n=None, seed=0, offset=0):
+def generate(pack, mi, x, k, times, temb_steps, dt, thermo_kind, gamma, delta_n=None, seed=0, offset=0, ctab=None):
     """In-place generation loop on x (B,N,3) and k (B,N,1)."""
     B, N = mi.B, mi.N
+    n_ctab = 0 if ctab is None else ctab.shape[1]
     call("mmb_fused_epic_generate", pack["variant"], B, N, f32(pack["packed"]), i32(pack["desc"]), pack["nb_branch"],
          pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"], pack["off_table"], f32(mi.maskf),
          i32(mi.counts), f32(x, "x"), i64(k, "k"), times.numel(), f32(times, "times"), f32(temb_steps, "temb_steps"),
-         _fl(dt), thermo_kind, _fl(gamma), f32(delta_n, "delta_n"), seed, offset, stream())
+         f32(ctab, "ctab"), n_ctab, _fl(dt), thermo_kind, _fl(gamma), f32(delta_n, "delta_n"), seed, offset, stream())
 
 
 def algorithmic_flops_per_particle(model):

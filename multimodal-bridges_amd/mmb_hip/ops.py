@@ -177,7 +177,7 @@ def rate_euler_jump_(logits, k, t, t_scalar, dt, thermo_kind, gamma, u=None, see
 
 
 # ------------------------------------------------------------------------ K-F
-LOSS_WS = 2 * 1024
+LOSS_WS = 2 * 2048
 
 
 def loss_fwd_bwd(head_c, head_d, t, xt, x0, x1, bridge_kind, k1, mi, vocab_freq, coef, want_grad=True):

@@ -327,8 +327,14 @@ class MultiModalBridgeMatching(nn.Module):
                 dn = (torch.stack(list(dn), 0) if isinstance(dn, (list, tuple)) else dn).contiguous().float()
             br = self.bridge_discrete
             state.continuous = state.continuous.contiguous()
-            fused_epic.generate(pack, mi, state.continuous, state.discrete, tv, self._time_embedding(tv), delta_t,
-                                br.thermo_kind, br.gamma, delta_n=dn, seed=self.seed, offset=(call_id << 16))
+            key = (steps, eps, str(dev))
+            if pack.get("grid_key") != key:                           # depends on weights + time grid only
+                temb_steps = self._time_embedding(tv)
+                pack["grid_key"], pack["grid"] = key, (temb_steps, fused_epic.time_vector_table(pack, temb_steps))
+            temb_steps, ctab = pack["grid"]
+            fused_epic.generate(pack, mi, state.continuous, state.discrete, tv, temb_steps, delta_t,
+                                br.thermo_kind, br.gamma, delta_n=dn, seed=self.seed, offset=(call_id << 16),
+                                ctab=ctab)
             state.time = torch.full((mi.B, mi.N, 1), times[-1], device=dev)
             return TensorMultiModal.stack([first, state], dim=0)
         was_training = self.training

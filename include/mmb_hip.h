@@ -276,8 +276,11 @@ int mmb_fused_epic_forward(int variant, int B, int N, const float* packed, const
  * are updated in place; padded slots move like real ones (K3).  times (steps) and temb_steps
  * (steps,Et) are device arrays; ctab_steps (steps,n_ctab,128) | NULL holds the precomputed time
  * vectors W_t temb of every layer that consumes the time embedding (t is the same for all jets
- * of a grid point, so this per-jet matvec is hoisted out of the kernel); delta_n (steps,B,N,V) injected Poisson counts or NULL for the
- * Philox jump sampler (seed, offset). */
+ * of a grid point, so this per-jet matvec is hoisted out of the kernel); delta_n (steps,B,N,V)
+ * injected Poisson counts or NULL for the Philox jump sampler (seed, offset).
+ * em != 0 replaces the Euler step by Euler-Maruyama (solvers.py:27-33, Q5-repaired diffusion
+ * sigma_t = em_sigma*sqrt(t(1-t)), NO sqrt(dt)): x += dt v + sigma_t dW with dW from delta_w
+ * (steps,B,N,3) or, when NULL, Philox + Box-Muller. */
 int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, const int32_t* desc,
                             int nb_branch, int nb_fused_exec, int use_skip,
                             int off_cw, int off_cb, int off_table,
@@ -285,7 +288,8 @@ int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, cons
                             int steps, const float* times, const float* temb_steps,
                             const float* ctab_steps, int n_ctab, float dt,
                             int thermo_kind, float gamma, const float* delta_n,
-                            uint64_t seed, uint64_t offset, void* stream);
+                            uint64_t seed, uint64_t offset,
+                            int em, float em_sigma, const float* delta_w, void* stream);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,23 @@ __device__ __forceinline__ void ffor(F&& f) { ffor_impl(f, std::make_integer_seq
 
 constexpr int FE_THREADS = 256;
 
+// Developer-only phase timing (build with MMB_EXTRA_FLAGS=-DMMB_FE_PROF, benchmarks/prof_fused.py):
+// thread 0 of block 0 accumulates core-clock cycles per phase category.
+#ifdef MMB_FE_PROF
+__device__ unsigned long long fe_prof[16];
+#define FE_PROF(L, cat)                                                        \
+  do {                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x == 0) {                                 \
+      const unsigned long long now_ = clock64();                               \
+      atomicAdd(&fe_prof[cat], now_ - (L).tlast);                              \
+      (L).tlast = now_;                                                        \
+    }                                                                          \
+  } while (0)
+#else
+#define FE_PROF(L, cat) do { } while (0)
+#endif
+enum { PF_EMBED = 0, PF_POOL, PF_GLOB1, PF_GLOB2, PF_DVEC, PF_LOC1, PF_LOC2, PF_EPI, PF_OUT, PF_PROJ_MMA, PF_HEAD, PF_STEP, PF_N };
+
 // ------------------------------------------------------------------ small helpers ------
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -84,46 +101,52 @@ struct alignas(16) Lds {
   float table[8 * 32];            // discrete embedding table [V<=8][Ed<=32]
   float cnt;
   int red[4];
+#ifdef MMB_FE_PROF
+  unsigned long long tlast;
+#endif
 };
 
 // out[o] = act( sum_k WT[k*O+o] * v[k] + bias[o] ) + add[o]   -- v/out/add live in LDS.
-// Each thread owns FOUR consecutive outputs (one dwordx4 per k) and every P-th k; up to 12 loads
-// are in flight per thread so the L2 latency of the weight stream is paid ~K/(12 P) times, not K/P.
-// O must be a multiple of 4 and O/4 <= 256.
-template <int ACT>
-__device__ void matvec(const float* __restrict__ WT, const float* __restrict__ bias, const float* v, int K, int O,
-                       float* out, const float* add, float* scratch, int tid) {
-  const int O4 = O >> 2;
-  int P = FE_THREADS / O4;                         // k-partitions
-  if (P > 64) P = 64;
-  const int o4 = tid % O4, part = tid / O4;
+// K and O are compile-time (O a power of two >= 8): each thread owns FOUR consecutive outputs (one
+// dwordx4 per k) and every P-th k; ALL of its ceil(K/P) weight loads (in groups of <= 12) are issued
+// before the first FMA, so the L2 latency of the weight stream is paid once per group.
+template <int ACT, int K, int O>
+__device__ __forceinline__ void matvec(const float* __restrict__ WT, const float* __restrict__ bias, const float* v,
+                                       float* out, const float* add, float* scratch, int tid) {
+  static_assert((O & (O - 1)) == 0 && O >= 8 && O <= 1024, "matvec: O must be a power of two");
+  constexpr int O4 = O / 4;
+  constexpr int P = (FE_THREADS / O4) > 64 ? 64 : (FE_THREADS / O4);   // k-partitions, P*O <= 1024
+  constexpr int ITER = (K + P - 1) / P;
+  constexpr int UN = 12;
+  const int o4 = tid & (O4 - 1), part = tid / O4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (part < P) {
     const float4* w4 = reinterpret_cast<const float4*>(WT) + o4;
-    int k = part;
-    constexpr int UN = 12;
-    for (; k + (UN - 1) * P < K; k += UN * P) {
-      float4 w[UN];
-#pragma unroll
-      for (int u = 0; u < UN; ++u) w[u] = w4[(int64_t)(k + u * P) * O4];
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const float vv = v[k + u * P];
-        s.x += w[u].x * vv; s.y += w[u].y * vv; s.z += w[u].z * vv; s.w += w[u].w * vv;
-      }
-    }
-    for (; k < K; k += P) {
-      const float4 w = w4[(int64_t)k * O4];
-      const float vv = v[k];
-      s.x += w.x * vv; s.y += w.y * vv; s.z += w.z * vv; s.w += w.w * vv;
-    }
+    ffor<(ITER + UN - 1) / UN>([&](auto cc) {
+      constexpr int c0 = decltype(cc)::v * UN;
+      constexpr int n = (ITER - c0) < UN ? (ITER - c0) : UN;
+      float4 w[n];
+      ffor<n>([&](auto uc) {
+        constexpr int it = c0 + decltype(uc)::v;
+        int kk = part + it * P;
+        if constexpr ((it + 1) * P > K) kk = kk < K ? kk : K - 1;          // only the ragged last round clamps
+        w[decltype(uc)::v] = w4[kk * O4];
+      });
+      ffor<n>([&](auto uc) {
+        constexpr int it = c0 + decltype(uc)::v;
+        const int kk = part + it * P;
+        float vv;
+        if constexpr ((it + 1) * P > K) vv = kk < K ? v[kk] : 0.0f; else vv = v[kk];
+        const float4 ww = w[decltype(uc)::v];
+        s.x += ww.x * vv; s.y += ww.y * vv; s.z += ww.z * vv; s.w += ww.w * vv;
+      });
+    });
+    *reinterpret_cast<float4*>(&scratch[part * O + 4 * o4]) = s;           // partitions -> LDS [part][O]
   }
-  // combine the P partitions: partitions live in different lanes/waves -> LDS, [part][O]
-  // (scratch holds P*O <= 1024 floats)
-  if (part < P) *reinterpret_cast<float4*>(&scratch[part * O + 4 * o4]) = s;
   __syncthreads();
   if (tid < O) {
     float t = bias ? bias[tid] : 0.0f;
+#pragma unroll
     for (int p = 0; p < P; ++p) t += scratch[p * O + tid];
     t = act_f<ACT>(t);
     if (add) t += add[tid];
@@ -198,17 +221,61 @@ __device__ __forceinline__ void act_tiles(f32x16 (&a)[OT]) {
     ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; a[ot][r] = act_f<ACT>(a[ot][r]); }); });
 }
 
+// exchange with the lane whose index differs in bit STEP (within the 32 lanes of a half)
+template <int STEP>
+__device__ __forceinline__ float lane_xchg(float v) {
+  if constexpr (STEP == 0) return dpp_mov<0xB1>(v);            // quad_perm [1,0,3,2]
+  else if constexpr (STEP == 1) return dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+  else if constexpr (STEP == 3) return dpp_mov<0x128>(v);      // row_ror:8 == xor 8 inside a row of 16
+  else if constexpr (STEP == 2)
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x101F));   // xor 4
+  else
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // xor 16
+}
+
+// One butterfly stage of the transpose-reduce: the pair (in[2j], in[2j+1]) is split between the two
+// lanes of an exchange pair -- the lane with bit STEP clear keeps the sum of in[2j], its partner
+// the sum of in[2j+1] -- so the number of live values halves while the number of lanes summed doubles.
+template <int N, int STEP>
+__device__ __forceinline__ void bfly_stage(const float (&in)[N], float (&out)[N / 2], bool bit) {
+  ffor<N / 2>([&](auto jc) {
+    constexpr int j = decltype(jc)::v;
+    const float keep = bit ? in[2 * j + 1] : in[2 * j];
+    const float send = bit ? in[2 * j] : in[2 * j + 1];
+    out[j] = keep + lane_xchg<STEP>(send);
+  });
+}
+
+// Masked column sums of this wave's 32 particles for all 32*HT features -> partial[wave][feature].
+// Transpose-reduce butterfly: 16*HT*(1/2+1/4+..) exchanges instead of 16*HT*5; afterwards lane l
+// holds the flat register indices idx = 32 j + (l & 31)  (idx = 16 t + r of tile t, register r).
 template <int HT>
 __device__ __forceinline__ void pool_partials(const f32x16 (&x)[HT], float m, float* partial, int wave, int lane) {
+  constexpr int N0 = 16 * HT;
   const int half = lane >> 5;
-  ffor<HT>([&](auto tc) {
-    constexpr int t = decltype(tc)::v;
-    ffor<16>([&](auto rc) {
-      constexpr int r = decltype(rc)::v;
-      float v = half_sum32(x[t][r] * m);
-      if ((lane & 31) == 0) partial[wave * 128 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half] = v;
+  float a0[N0];
+  ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+    ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; a0[16 * t + r] = x[t][r] * m; }); });
+  float a1[N0 / 2], a2[N0 / 4], a3[N0 / 8], a4[N0 / 16];
+  bfly_stage<N0, 0>(a0, a1, (lane & 1) != 0);
+  bfly_stage<N0 / 2, 1>(a1, a2, (lane & 2) != 0);
+  bfly_stage<N0 / 4, 2>(a2, a3, (lane & 4) != 0);
+  bfly_stage<N0 / 8, 3>(a3, a4, (lane & 8) != 0);
+  float* dst = partial + wave * 128;
+  if constexpr (HT == 1) {                         // one value left: plain sum over the last lane bit
+    const float v = a4[0] + lane_xchg<4>(a4[0]);
+    const int r = lane & 15;
+    if ((lane & 16) == 0) dst[(r & 3) + 8 * (r >> 2) + 4 * half] = v;
+  } else {
+    float a5[N0 / 32];
+    bfly_stage<N0 / 16, 4>(a4, a5, (lane & 16) != 0);
+    ffor<N0 / 32>([&](auto jc) {
+      constexpr int j = decltype(jc)::v;
+      const int idx = 32 * j + (lane & 31);
+      const int t = idx >> 4, r = idx & 15;
+      dst[32 * t + (r & 3) + 8 * (r >> 2) + 4 * half] = a5[j];
     });
-  });
+  }
 }
 
 // pooled = [sum/cnt, 0.01*sum, tail]   (epic.py:100-107)
@@ -225,48 +292,55 @@ __device__ __forceinline__ void build_pooled(int H, int T, const float* tail, Ld
 
 // time vector c = W_t temb of a layer: taken from the per-grid-point table when the caller
 // precomputed it (generation: t is the same for every jet), else a matvec into L.cvec.
-__device__ __forceinline__ const float* time_vec(const float* ctab, int& ci, const float* WtT, int ET, int O, Lds& L,
-                                                 int tid) {
+template <int ET, int O>
+__device__ __forceinline__ const float* time_vec(const float* ctab, int& ci, const float* WtT, Lds& L, int tid) {
   if (ctab != nullptr) {
     const float* c = ctab + (int64_t)ci * 128;
     ++ci;
     return c;
   }
-  matvec<MMB_ACT_NONE>(WtT, nullptr, L.temb, ET, O, L.cvec, nullptr, L.scratch, tid);
+  matvec<MMB_ACT_NONE, ET, O>(WtT, nullptr, L.temb, L.cvec, nullptr, L.scratch, tid);
   return L.cvec;
 }
 
 // ------------------------------------------------------------------ one EPiC encoder ----
 // x: HT tiles (in/out), skip: HT tiles.  Global vector in L.gcur.  `li` walks the descriptors.
-template <int HT, int ET>
+template <int HT, int ET, int G>
 struct Epic {
   static constexpr int H = 32 * HT;
 
   // EPiCLayer (epic.py:187-208) + the encoder-level skip add (:89-90).  skipf(IF<t>) yields skip tile t.
   template <typename SkipFn>
-  static __device__ __forceinline__ void layer(f32x16 (&x)[HT], SkipFn&& skipf, bool use_skip, int G,
+  static __device__ __forceinline__ void layer(f32x16 (&x)[HT], SkipFn&& skipf, bool use_skip,
                                                const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
                                                float m, int tid, const float* ctab, int& ci) {
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const LDesc g1 = D[li], g2 = D[li + 1], l1 = D[li + 2], l2 = D[li + 3];
     li += 4;
+    FE_PROF(L, PF_EPI);
     pool_partials<HT>(x, m, L.partial, wave, lane);
     build_pooled(H, G, L.gcur, L, tid);
-    matvec<MMB_ACT_LRELU>(P + g1.wt, P + g1.b, L.pooled, 2 * H + G, H, L.gh, nullptr, L.scratch, tid);
-    matvec<MMB_ACT_NONE>(P + g2.wt, P + g2.b, L.gh, H, G, L.gnew, L.gcur, L.scratch, tid);   // g' = g + fc_glob2(.)
-    const float* cv = time_vec(ctab, ci, P + l1.wt, ET, H, L, tid);
-    matvec<MMB_ACT_NONE>(P + l1.wg, P + l1.b, L.gnew, G, H, L.dvec, nullptr, L.scratch, tid);
+    FE_PROF(L, PF_POOL);
+    matvec<MMB_ACT_LRELU, 2 * H + G, H>(P + g1.wt, P + g1.b, L.pooled, L.gh, nullptr, L.scratch, tid);
+    FE_PROF(L, PF_GLOB1);
+    matvec<MMB_ACT_NONE, H, G>(P + g2.wt, P + g2.b, L.gh, L.gnew, L.gcur, L.scratch, tid);   // g' = g + fc_glob2(.)
+    FE_PROF(L, PF_GLOB2);
+    const float* cv = time_vec<ET, H>(ctab, ci, P + l1.wt, L, tid);
+    matvec<MMB_ACT_NONE, G, H>(P + l1.wg, P + l1.b, L.gnew, L.dvec, nullptr, L.scratch, tid);
+    FE_PROF(L, PF_DVEC);
     if (tid < G) L.gcur[tid] = lrelu_f(L.gnew[tid]) + (use_skip ? L.gskip[tid] : 0.0f);
     f32x16 lh[HT];
     acc_init<HT>(lh, m, cv, L.dvec, half);
     mma_x<HT, HT>(lh, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, P + l1.wx, lane);
     act_tiles<HT, MMB_ACT_LRELU>(lh);
+    FE_PROF(L, PF_LOC1);
     // x <- (x + b2) + W2 lh : the residual rides in the accumulator, x's registers ARE the accumulator
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
       ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
         const float4 bv = *reinterpret_cast<const float4*>(P + l2.b + 32 * t + 8 * q + 4 * half);
         x[t][4 * q + 0] += bv.x; x[t][4 * q + 1] += bv.y; x[t][4 * q + 2] += bv.z; x[t][4 * q + 3] += bv.w; }); });
     mma_x<HT, HT>(x, [&](auto fc) -> const f32x16& { return lh[decltype(fc)::v]; }, P + l2.wx, lane);
+    FE_PROF(L, PF_LOC2);
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
       if (use_skip) {
         const f32x16 sk = skipf(IF<t>{});
@@ -275,29 +349,31 @@ struct Epic {
         ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; x[t][r] = lrelu_f(x[t][r]); });
       } });
     __syncthreads();                                   // gcur settled before the next pooled build
+    FE_PROF(L, PF_EPI);
   }
 
   // output layer: wn Linear on cat[t, x, g] (epic.py:93-96)
-  static __device__ __forceinline__ void output(f32x16 (&out)[HT], const f32x16 (&x)[HT], int G,
+  static __device__ __forceinline__ void output(f32x16 (&out)[HT], const f32x16 (&x)[HT],
                                                 const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
                                                 float m, int tid, const float* ctab, int& ci) {
     const int lane = tid & 63, half = lane >> 5;
     const LDesc o = D[li];
     li += 1;
-    const float* cv = time_vec(ctab, ci, P + o.wt, ET, H, L, tid);
-    matvec<MMB_ACT_NONE>(P + o.wg, P + o.b, L.gcur, G, H, L.dvec, nullptr, L.scratch, tid);
+    const float* cv = time_vec<ET, H>(ctab, ci, P + o.wt, L, tid);
+    matvec<MMB_ACT_NONE, G, H>(P + o.wg, P + o.b, L.gcur, L.dvec, nullptr, L.scratch, tid);
     acc_init<HT>(out, m, cv, L.dvec, half);
     mma_x<HT, HT>(out, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, P + o.wx, lane);
+    FE_PROF(L, PF_OUT);
   }
 
   // EPiCProjection (epic.py:145-159) from ONE padded input tile
-  static __device__ __forceinline__ void project(f32x16 (&x)[HT], const f32x16& xin, int G,
+  static __device__ __forceinline__ void project(f32x16 (&x)[HT], const f32x16& xin,
                                                  const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
                                                  float m, int tid, const float* ctab, int& ci) {
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const LDesc p0 = D[li], p2 = D[li + 1], q0 = D[li + 2], q2 = D[li + 3];
     li += 4;
-    const float* cv = time_vec(ctab, ci, P + p0.wt, ET, H, L, tid);
+    const float* cv = time_vec<ET, H>(ctab, ci, P + p0.wt, L, tid);
     f32x16 h[HT];
     acc_init<HT>(h, m, cv, P + p0.b, half);
     mma_x<1, HT>(h, [&](auto) -> const f32x16& { return xin; }, P + p0.wx, lane);
@@ -305,10 +381,12 @@ struct Epic {
     acc_init<HT>(x, 0.0f, nullptr, P + p2.b, half);
     mma_x<HT, HT>(x, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, P + p2.wx, lane);
     act_tiles<HT, MMB_ACT_GELU>(x);
+    FE_PROF(L, PF_PROJ_MMA);
     pool_partials<HT>(x, m, L.partial, wave, lane);
     build_pooled(H, ET, L.temb, L, tid);               // context = time embedding (dim_context = Et)
-    matvec<MMB_ACT_GELU>(P + q0.wt, P + q0.b, L.pooled, 2 * H + ET, H, L.gh, nullptr, L.scratch, tid);
-    matvec<MMB_ACT_GELU>(P + q2.wt, P + q2.b, L.gh, H, G, L.gcur, nullptr, L.scratch, tid);
+    matvec<MMB_ACT_GELU, 2 * H + ET, H>(P + q0.wt, P + q0.b, L.pooled, L.gh, nullptr, L.scratch, tid);
+    matvec<MMB_ACT_GELU, H, G>(P + q2.wt, P + q2.b, L.gh, L.gcur, nullptr, L.scratch, tid);
+    FE_PROF(L, PF_GLOB1);
   }
 };
 
@@ -361,20 +439,22 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
   const int lane = tid & 63, half = lane >> 5;
   int li = 0, ci = 0;
   f32x16 tc, td;
+  FE_PROF(L, PF_STEP);
   embed_tiles<DM>(tc, td, xp, kp, m, L, half);
+  FE_PROF(L, PF_EMBED);
   // S (LDS, HFT tiles) = cat[h1, h2]: fused-encoder input, its skip connection AND the heads' input
   // ---- two branch encoders (multimodal_epic.py:173-175)
   ffor<2>([&](auto bc) {
     constexpr int br = decltype(bc)::v;
     f32x16 x[HBT], sk[HBT], out[HBT];
-    Epic<HBT, DM::ET>::project(x, br == 0 ? tc : td, DM::GB, A.P, A.D, li, L, m, tid, A.ctab, ci);
+    Epic<HBT, DM::ET, DM::GB>::project(x, br == 0 ? tc : td, A.P, A.D, li, L, m, tid, A.ctab, ci);
     if (tid < DM::GB) L.gskip[tid] = L.gcur[tid];
     ffor<HBT>([&](auto t) { sk[decltype(t)::v] = x[decltype(t)::v]; });
     __syncthreads();
     for (int i = 0; i < A.nb_branch; ++i)
-      Epic<HBT, DM::ET>::layer(x, [&](auto t) -> const f32x16& { return sk[decltype(t)::v]; }, A.use_skip != 0,
-                               DM::GB, A.P, A.D, li, L, m, tid, A.ctab, ci);
-    Epic<HBT, DM::ET>::output(out, x, DM::GB, A.P, A.D, li, L, m, tid, A.ctab, ci);
+      Epic<HBT, DM::ET, DM::GB>::layer(x, [&](auto t) -> const f32x16& { return sk[decltype(t)::v]; },
+                                       A.use_skip != 0, A.P, A.D, li, L, m, tid, A.ctab, ci);
+    Epic<HBT, DM::ET, DM::GB>::output(out, x, A.P, A.D, li, L, m, tid, A.ctab, ci);
     ffor<HBT>([&](auto t) { park_tile(S, br * HBT + decltype(t)::v, out[decltype(t)::v], tid); });
     if (tid < DM::GB) L.gcat[br * DM::GB + tid] = L.gcur[tid];
     __syncthreads();
@@ -385,15 +465,16 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
   f32x16 x[HFT], f[HFT];
   ffor<HFT>([&](auto t) { x[decltype(t)::v] = fetch_tile(S, decltype(t)::v, tid); });
   for (int i = 0; i < A.nb_fused_exec; ++i)
-    Epic<HFT, DM::ET>::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, decltype(t)::v, tid); }, A.use_skip != 0,
-                             DM::GF, A.P, A.D, li, L, m, tid, A.ctab, ci);
-  Epic<HFT, DM::ET>::output(f, x, DM::GF, A.P, A.D, li, L, m, tid, A.ctab, ci);
+    Epic<HFT, DM::ET, DM::GF>::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, decltype(t)::v, tid); },
+                                     A.use_skip != 0, A.P, A.D, li, L, m, tid, A.ctab, ci);
+  Epic<HFT, DM::ET, DM::GF>::output(f, x, A.P, A.D, li, L, m, tid, A.ctab, ci);
   // ---- heads (multimodal_epic.py:187-189): cat[t, f_i, h_i] -> GELU -> out
   const LDesc c0 = A.D[li], c2 = A.D[li + 1], d0 = A.D[li + 2], d2 = A.D[li + 3];
+  FE_PROF(L, PF_EPI);
   const int ci_heads = ci;                               // table slots: [.. , continuous head, discrete head]
   if (which != 1) {
     ci = ci_heads;
-    const float* cv = time_vec(A.ctab, ci, A.P + c0.wt, DM::ET, DM::HB, L, tid);
+    const float* cv = time_vec<DM::ET, DM::HB>(A.ctab, ci, A.P + c0.wt, L, tid);
     f32x16 h[HBT];
     acc_init<HBT>(h, m, cv, A.P + c0.b, half);
     mma_x<HFT, HBT>(h, [&](auto fc) -> f32x16 {
@@ -407,7 +488,7 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
   }
   if (which != 0) {
     ci = ci_heads + 1;
-    const float* cv = time_vec(A.ctab, ci, A.P + d0.wt, DM::ET, DM::HB, L, tid);
+    const float* cv = time_vec<DM::ET, DM::HB>(A.ctab, ci, A.P + d0.wt, L, tid);
     f32x16 h[HBT];
     acc_init<HBT>(h, m, cv, A.P + d0.b, half);
     mma_x<HFT, HBT>(h, [&](auto fc) -> f32x16 {
@@ -419,6 +500,7 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
     mma_x<HBT, 1>(o, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, A.P + d2.wx, lane);
     hd = o[0];
   }
+  FE_PROF(L, PF_HEAD);
 }
 
 template <class DM>
@@ -502,6 +584,9 @@ struct GenArgs {
   float thermo_c;            // fp32(-V*gamma)
   const float* delta_n;      // (steps,B,N,V) injected Poisson counts or NULL -> Philox
   uint64_t seed, offset;
+  int em;                    // 1: Euler-Maruyama  x += dt v + sigma sqrt(t(1-t)) dW  (solvers.py:27-33, no sqrt(dt))
+  float em_sigma;
+  const float* delta_w;      // (steps,B,N,DC) injected Wiener increments or NULL -> Philox/Box-Muller
 };
 
 __device__ __forceinline__ float thermo_w_f(int kind, float c, float t0, float t1) { return thermo_w(kind, c, t0, t1); }
@@ -513,6 +598,9 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
   __shared__ float4 S[DM::HFT * 4 * FE_THREADS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   constexpr int V = DM::V;
+#ifdef MMB_FE_PROF
+  if (tid == 0) L.tlast = clock64();
+#endif
   load_constants<DM>(A, L, tid);
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
     __syncthreads();
@@ -536,11 +624,28 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
       forward_jet<DM>(A, L, S, xp, kp, m, 0, hc, hd, tid);
       {
         float v[3] = {hc[0], hc[1], hc[2]};
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+        float sig = 0.0f;
+        if (Gn.em) {                                     // both lane halves draw the same increments
+          sig = Gn.em_sigma * sqrtf(tt * (1.0f - tt));
+          if (Gn.delta_w != nullptr) {
+            if (valid) {
+              const float* dw = Gn.delta_w + (((int64_t)s * A.B + b) * A.N + p) * DM::DC;
+#pragma unroll
+              for (int d = 0; d < DM::DC; ++d) w[d] = dw[d];
+            }
+          } else {
+            uint32_t q[4];
+            philox4(Gn.seed, Gn.offset + (uint64_t)s, (uint64_t)gp, 0xE001u, q);
+            box_muller(q[0], q[1], w[0], w[1]);
+            box_muller(q[2], q[3], w[2], w[3]);
+          }
+        }
 #pragma unroll
         for (int d = 0; d < DM::DC; ++d) {
           const float o = __shfl_xor(v[d], 32, 64);
           const float drift = half == 0 ? v[d] : o;
-          xp[d] += Gn.dt * drift;
+          xp[d] += Gn.em ? (Gn.dt * drift + sig * w[d]) : Gn.dt * drift;
         }
       }
       __syncthreads();
@@ -645,13 +750,23 @@ extern "C" int mmb_fused_epic_forward(int variant, int B, int N, const float* pa
   return check_launch("mmb_fused_epic_forward");
 }
 
+#ifdef MMB_FE_PROF
+extern "C" int mmb_debug_fused_prof(unsigned long long* out16, int reset) {
+  if (reset) {
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(fe_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+  }
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(fe_prof), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, const int32_t* desc,
                                        int nb_branch, int nb_fused_exec, int use_skip, int off_cw, int off_cb,
                                        int off_table, const float* maskf, const int32_t* counts, float* x, int64_t* k,
                                        int steps, const float* times, const float* temb_steps,
                                        const float* ctab_steps, int n_ctab, float dt,
                                        int thermo_kind, float gamma, const float* delta_n, uint64_t seed,
-                                       uint64_t offset, void* stream) {
+                                       uint64_t offset, int em, float em_sigma, const float* delta_w, void* stream) {
   int rc = check_fused("mmb_fused_epic_generate", B, N, packed, desc, maskf, counts);
   if (rc) return rc;
   MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_epic_generate: unknown variant %d", variant);
@@ -659,7 +774,8 @@ extern "C" int mmb_fused_epic_generate(int variant, int B, int N, const float* p
   MMB_REQUIRE(thermo_kind >= 0 && thermo_kind <= 4, "mmb_fused_epic_generate: bad thermostat");
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
               off_table, B, N, maskf, counts};
-  GenArgs Gn{steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, (float)(-(double)8 * (double)gamma), delta_n, seed, offset};
+  GenArgs Gn{steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, (float)(-(double)8 * (double)gamma), delta_n, seed, offset,
+             em, em_sigma, delta_w};
   const int grid = B < 4096 ? B : 4096;
   if (variant == 0)
     hipLaunchKernelGGL(fused_generate_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k);

@@ -10,7 +10,7 @@ CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 LIB = os.path.join(HERE, "libmmb_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+         "-Wno-unused-variable", "-Wno-unused-but-set-variable"] + os.environ.get("MMB_EXTRA_FLAGS", "").split()
 
 
 def sources():

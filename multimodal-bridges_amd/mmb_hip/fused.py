@@ -166,14 +166,17 @@ def forward(pack, mi, x, k, temb, which, temb_stride=None):
     return hc, hd
 
 
-def generate(pack, mi, x, k, times, temb_steps, dt, thermo_kind, gamma, delta_n=None, seed=0, offset=0, ctab=None):
-    """In-place generation loop on x (B,N,3) and k (B,N,1)."""
+def generate(pack, mi, x, k, times, temb_steps, dt, thermo_kind, gamma, delta_n=None, seed=0, offset=0, ctab=None,
+             em_sigma=None, delta_w=None):
+    """In-place generation loop on x (B,N,3) and k (B,N,1).  em_sigma is None -> Euler, else
+    Euler-Maruyama with sigma_t = em_sigma*sqrt(t(1-t)) and increments delta_w (steps,B,N,3) | Philox."""
     B, N = mi.B, mi.N
     n_ctab = 0 if ctab is None else ctab.shape[1]
     call("mmb_fused_epic_generate", pack["variant"], B, N, f32(pack["packed"]), i32(pack["desc"]), pack["nb_branch"],
          pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"], pack["off_table"], f32(mi.maskf),
          i32(mi.counts), f32(x, "x"), i64(k, "k"), times.numel(), f32(times, "times"), f32(temb_steps, "temb_steps"),
-         f32(ctab, "ctab"), n_ctab, _fl(dt), thermo_kind, _fl(gamma), f32(delta_n, "delta_n"), seed, offset, stream())
+         f32(ctab, "ctab"), n_ctab, _fl(dt), thermo_kind, _fl(gamma), f32(delta_n, "delta_n"), seed, offset,
+         0 if em_sigma is None else 1, _fl(0.0 if em_sigma is None else em_sigma), f32(delta_w, "delta_w"), stream())
 
 
 def algorithmic_flops_per_particle(model):

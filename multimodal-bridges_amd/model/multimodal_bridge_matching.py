@@ -316,8 +316,9 @@ class MultiModalBridgeMatching(nn.Module):
             state.discrete = state.discrete.clone()                   # the source tokens stay intact
         mi = self._mask_info(state)
         pack = self._fused_pack() if (state.has_continuous and state.has_discrete) else None
-        only_dn = noise is None or set(noise.keys()) <= {"delta_n"}
-        if (pack is not None and cfg.solver_continuous == "euler" and cfg.solver_discrete == "tauleap" and only_dn):
+        only_dn = noise is None or set(noise.keys()) <= {"delta_n", "delta_w"}
+        if (pack is not None and cfg.solver_continuous in ("euler", "euler_maruyama")
+                and cfg.solver_discrete == "tauleap" and only_dn):
             # ONE launch for the whole loop: per-jet workgroups keep the state in registers
             dev = state.mask.device
             tv = grid.to(dev)
@@ -325,6 +326,13 @@ class MultiModalBridgeMatching(nn.Module):
             if noise and "delta_n" in noise:
                 dn = noise["delta_n"]
                 dn = (torch.stack(list(dn), 0) if isinstance(dn, (list, tuple)) else dn).contiguous().float()
+            em_sigma, dw = None, None
+            if cfg.solver_continuous == "euler_maruyama":             # diffusion: sigma*sqrt(t(1-t)) for the
+                bc = self.bridge_continuous                           # Schrodinger bridge, 0 for UniformFlow
+                em_sigma = float(bc.sigma) if getattr(bc, "kind", 0) == 1 else 0.0
+                if noise and "delta_w" in noise:
+                    dw = noise["delta_w"]
+                    dw = (torch.stack(list(dw), 0) if isinstance(dw, (list, tuple)) else dw).contiguous().float()
             br = self.bridge_discrete
             state.continuous = state.continuous.contiguous()
             key = (steps, eps, str(dev))
@@ -334,7 +342,7 @@ class MultiModalBridgeMatching(nn.Module):
             temb_steps, ctab = pack["grid"]
             fused_epic.generate(pack, mi, state.continuous, state.discrete, tv, temb_steps, delta_t,
                                 br.thermo_kind, br.gamma, delta_n=dn, seed=self.seed, offset=(call_id << 16),
-                                ctab=ctab)
+                                ctab=ctab, em_sigma=em_sigma, delta_w=dw)
             state.time = torch.full((mi.B, mi.N, 1), times[-1], device=dev)
             return TensorMultiModal.stack([first, state], dim=0)
         was_training = self.training

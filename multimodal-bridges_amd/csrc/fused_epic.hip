@@ -92,9 +92,7 @@ struct LDesc {
 struct alignas(16) Lds {
   float temb[128];
   float gcur[64], gskip[64], gnew[64], gcat[64];
-  float pooled[2 * 128 + 128];
   float partial[4 * 128];
-  float scratch[4 * FE_THREADS];
   float gh[128];
   float cvec[128], dvec[128];
   float cw[32 * 4], cb[32];       // continuous embedding weight [Ec][Dc<=4], bias
@@ -106,53 +104,89 @@ struct alignas(16) Lds {
 #endif
 };
 
-// out[o] = act( sum_k WT[k*O+o] * v[k] + bias[o] ) + add[o]   -- v/out/add live in LDS.
-// K and O are compile-time (O a power of two >= 8): each thread owns FOUR consecutive outputs (one
-// dwordx4 per k) and every P-th k; ALL of its ceil(K/P) weight loads (in groups of <= 12) are issued
-// before the first FMA, so the L2 latency of the weight stream is paid once per group.
-template <int ACT, int K, int O>
-__device__ __forceinline__ void matvec(const float* __restrict__ WT, const float* __restrict__ bias, const float* v,
-                                       float* out, const float* add, float* scratch, int tid) {
-  static_assert((O & (O - 1)) == 0 && O >= 8 && O <= 1024, "matvec: O must be a power of two");
-  constexpr int O4 = O / 4;
-  constexpr int P = (FE_THREADS / O4) > 64 ? 64 : (FE_THREADS / O4);   // k-partitions, P*O <= 1024
-  constexpr int ITER = (K + P - 1) / P;
-  constexpr int UN = 12;
-  const int o4 = tid & (O4 - 1), part = tid / O4;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (part < P) {
-    const float4* w4 = reinterpret_cast<const float4*>(WT) + o4;
+// exchange with the lane whose index differs in bit BIT
+template <int BIT>
+__device__ __forceinline__ float lane_xchg(float v) {
+  if constexpr (BIT == 0) return dpp_mov<0xB1>(v);            // quad_perm [1,0,3,2]
+  else if constexpr (BIT == 1) return dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+  else if constexpr (BIT == 3) return dpp_mov<0x128>(v);      // row_ror:8 == xor 8 inside a row of 16
+  else if constexpr (BIT == 2)
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x101F));   // xor 4
+  else if constexpr (BIT == 4)
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // xor 16
+  else return __shfl_xor(v, 32, 64);
+}
+
+constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x / 2); }
+
+// Per-jet matvec  out[o] = act( sum_k WT[k*O+o] v(k) + bias[o] ) + add[o]  with ONE barrier.
+// The O outputs are split over the 4 waves (OW each); inside a wave lane = part*G + og: og picks VW
+// consecutive outputs (one dwordx4/x2 per k), part picks every PARTS-th k.  The PARTS partial sums
+// live in lanes of the SAME wave and are folded with lane exchanges (no LDS round trip, no barrier);
+// the only barrier publishes `out` to the other waves.  vfn(k) yields the input element (LDS).
+template <int K, int O>
+struct WaveMV {
+  static_assert((O & (O - 1)) == 0 && O >= 8 && O <= 256, "WaveMV: O must be a power of two in [8,256]");
+  static constexpr int OW = O / 4;                       // outputs per wave
+  static constexpr int VW = OW >= 4 ? 4 : OW;            // outputs per lane
+  static constexpr int G = OW / VW;                      // lane groups along the outputs
+  static constexpr int PARTS = 64 / G;                   // k-partitions inside the wave
+  static constexpr int ITER = (K + PARTS - 1) / PARTS;
+  static constexpr bool RAGGED = (K % PARTS) != 0;
+  typedef float vec __attribute__((ext_vector_type(VW)));
+
+  template <int ACT, typename VFn>
+  static __device__ __forceinline__ void run(const float* __restrict__ WT, const float* __restrict__ bias, VFn&& vfn,
+                                             float* out, const float* add, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int og = lane & (G - 1), part = lane / G;
+    const int o0 = wave * OW + og * VW;
+    const vec* wp = reinterpret_cast<const vec*>(WT + o0);
+    vec bv;
+    ffor<VW>([&](auto ec) { bv[decltype(ec)::v] = 0.0f; });
+    if (bias != nullptr && part == 0) bv = *reinterpret_cast<const vec*>(bias + o0);
+    vec acc;
+    ffor<VW>([&](auto ec) { acc[decltype(ec)::v] = 0.0f; });
+    constexpr int UN = 12;                               // loads in flight per lane
     ffor<(ITER + UN - 1) / UN>([&](auto cc) {
       constexpr int c0 = decltype(cc)::v * UN;
       constexpr int n = (ITER - c0) < UN ? (ITER - c0) : UN;
-      float4 w[n];
-      ffor<n>([&](auto uc) {
-        constexpr int it = c0 + decltype(uc)::v;
-        int kk = part + it * P;
-        if constexpr ((it + 1) * P > K) kk = kk < K ? kk : K - 1;          // only the ragged last round clamps
-        w[decltype(uc)::v] = w4[kk * O4];
+      vec w[n];
+      ffor<n>([&](auto ic) {
+        constexpr int it = c0 + decltype(ic)::v;
+        int kk = part + it * PARTS;
+        if constexpr (RAGGED && it == ITER - 1) kk = kk < K ? kk : K - 1;
+        w[decltype(ic)::v] = wp[kk * (O / VW)];
       });
-      ffor<n>([&](auto uc) {
-        constexpr int it = c0 + decltype(uc)::v;
-        const int kk = part + it * P;
+      ffor<n>([&](auto ic) {
+        constexpr int it = c0 + decltype(ic)::v;
+        const int kk = part + it * PARTS;
         float vv;
-        if constexpr ((it + 1) * P > K) vv = kk < K ? v[kk] : 0.0f; else vv = v[kk];
-        const float4 ww = w[decltype(uc)::v];
-        s.x += ww.x * vv; s.y += ww.y * vv; s.z += ww.z * vv; s.w += ww.w * vv;
+        if constexpr (RAGGED && it == ITER - 1) vv = kk < K ? vfn(kk) : 0.0f; else vv = vfn(kk);
+        acc += w[decltype(ic)::v] * vv;
       });
     });
-    *reinterpret_cast<float4*>(&scratch[part * O + 4 * o4]) = s;           // partitions -> LDS [part][O]
+    // fold the PARTS partitions: lane bits log2(G) .. 5
+    ffor<6 - ilog2(G)>([&](auto bc) {
+      constexpr int bit = ilog2(G) + decltype(bc)::v;
+      ffor<VW>([&](auto ec) { constexpr int e = decltype(ec)::v; acc[e] += lane_xchg<bit>(acc[e]); });
+    });
+    if (part == 0) {
+      ffor<VW>([&](auto ec) {
+        constexpr int e = decltype(ec)::v;
+        float t = act_f<ACT>(acc[e] + bv[e]);
+        if (add) t += add[o0 + e];
+        out[o0 + e] = t;
+      });
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (tid < O) {
-    float t = bias ? bias[tid] : 0.0f;
-#pragma unroll
-    for (int p = 0; p < P; ++p) t += scratch[p * O + tid];
-    t = act_f<ACT>(t);
-    if (add) t += add[tid];
-    out[tid] = t;
-  }
-  __syncthreads();
+};
+
+template <int ACT, int K, int O>
+__device__ __forceinline__ void matvec(const float* __restrict__ WT, const float* __restrict__ bias, const float* v,
+                                       float* out, const float* add, int tid) {
+  WaveMV<K, O>::template run<ACT>(WT, bias, [&](int k) { return v[k]; }, out, add, tid);
 }
 
 // A lane's 16 values of tile t parked in / fetched from LDS: slot (t,q) holds one float4 per thread.
@@ -168,31 +202,55 @@ __device__ __forceinline__ f32x16 fetch_tile(const float4* S, int t, int tid) {
   return v;
 }
 
-// acc[ot] += W_x (tile rows ot) * X^T, X^T tiles delivered by `tile(IF<ft>)` (a reference to
-// registers, or a value fetched from LDS).
-template <int KT, int OT, typename TileFn>
-__device__ __forceinline__ void mma_x(f32x16 (&acc)[OT], TileFn&& tile, const float* __restrict__ Wp, int lane) {
+// First A-operand group (k-steps 0..3 of every output tile) of a packed weight matrix, fetched
+// ahead of the GEMM that uses it -- while the previous GEMM or the per-jet chain runs -- so that no
+// GEMM starts with an exposed L2 round trip.
+template <int OT>
+struct AFrag {
+  float4 a[OT];
+};
+template <int OT>
+__device__ __forceinline__ void mma_prefetch(AFrag<OT>& f, const float* __restrict__ Wp, int lane) {
   const float4* w4 = reinterpret_cast<const float4*>(Wp) + lane;
-  float4 a_cur[OT], a_nxt[OT];
-  ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; a_cur[ot] = w4[ot * 64]; });
+  ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; f.a[ot] = w4[ot * 64]; });
+}
+
+// acc[ot] += W_x (tile rows ot) * X^T, X^T tiles delivered by `tile(IF<ft>)` (a reference to
+// registers, or a value fetched from LDS).  A-operand groups (4 k-steps x OT tiles, one dwordx4 per
+// lane and tile) run D groups ahead of the MFMAs through a ring of D+1 register buffers; D is
+// chosen so that the look-ahead is ~1000 MFMA cycles whatever OT is.
+template <int KT, int OT, typename TileFn>
+__device__ __forceinline__ void mma_x(f32x16 (&acc)[OT], TileFn&& tile, const float* __restrict__ Wp, int lane,
+                                      const AFrag<OT>& pre) {
+  constexpr int NG = KT * 4;
+  constexpr int D0 = OT >= 4 ? 1 : (OT == 2 ? 2 : 4);
+  constexpr int D = D0 < NG - 1 ? D0 : (NG - 1 > 0 ? NG - 1 : 1);
+  const float4* w4 = reinterpret_cast<const float4*>(Wp) + lane;
+  float4 ring[D + 1][OT];
+  ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; ring[0][ot] = pre.a[ot]; });
+  ffor<D - 1>([&](auto dc) {
+    constexpr int g = 1 + decltype(dc)::v;
+    if constexpr (g < NG)
+      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; ring[g][ot] = w4[(g * OT + ot) * 64]; });
+  });
   ffor<KT>([&](auto fc) {
     constexpr int ft = decltype(fc)::v;
     decltype(auto) xt = tile(IF<ft>{});
     ffor<4>([&](auto qc) {
       constexpr int q = decltype(qc)::v;          // group = (ft, q): four k-steps r = 4q..4q+3
       constexpr int g = ft * 4 + q;
-      if constexpr (g + 1 < KT * 4)
-        ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; a_nxt[ot] = w4[((g + 1) * OT + ot) * 64]; });
+      constexpr int cur = g % (D + 1);
+      if constexpr (g + D < NG)
+        ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+          ring[(g + D) % (D + 1)][ot] = w4[((g + D) * OT + ot) * 64]; });
       ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ot].x, xt[4 * q + 0], acc[ot], 0, 0, 0); });
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[cur][ot].x, xt[4 * q + 0], acc[ot], 0, 0, 0); });
       ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ot].y, xt[4 * q + 1], acc[ot], 0, 0, 0); });
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[cur][ot].y, xt[4 * q + 1], acc[ot], 0, 0, 0); });
       ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ot].z, xt[4 * q + 2], acc[ot], 0, 0, 0); });
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[cur][ot].z, xt[4 * q + 2], acc[ot], 0, 0, 0); });
       ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ot].w, xt[4 * q + 3], acc[ot], 0, 0, 0); });
-      if constexpr (g + 1 < KT * 4)
-        ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; a_cur[ot] = a_nxt[ot]; });
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[cur][ot].w, xt[4 * q + 3], acc[ot], 0, 0, 0); });
     });
   });
 }
@@ -219,18 +277,6 @@ template <int OT, int ACT>
 __device__ __forceinline__ void act_tiles(f32x16 (&a)[OT]) {
   ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
     ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; a[ot][r] = act_f<ACT>(a[ot][r]); }); });
-}
-
-// exchange with the lane whose index differs in bit STEP (within the 32 lanes of a half)
-template <int STEP>
-__device__ __forceinline__ float lane_xchg(float v) {
-  if constexpr (STEP == 0) return dpp_mov<0xB1>(v);            // quad_perm [1,0,3,2]
-  else if constexpr (STEP == 1) return dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
-  else if constexpr (STEP == 3) return dpp_mov<0x128>(v);      // row_ror:8 == xor 8 inside a row of 16
-  else if constexpr (STEP == 2)
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x101F));   // xor 4
-  else
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // xor 16
 }
 
 // One butterfly stage of the transpose-reduce: the pair (in[2j], in[2j+1]) is split between the two
@@ -278,17 +324,19 @@ __device__ __forceinline__ void pool_partials(const f32x16 (&x)[HT], float m, fl
   }
 }
 
-// pooled = [sum/cnt, 0.01*sum, tail]   (epic.py:100-107)
-__device__ __forceinline__ void build_pooled(int H, int T, const float* tail, Lds& L, int tid) {
-  __syncthreads();
-  if (tid < H) {
-    const float s = (L.partial[tid] + L.partial[128 + tid]) + (L.partial[256 + tid] + L.partial[384 + tid]);
-    L.pooled[tid] = s / L.cnt;
-    L.pooled[H + tid] = s * 0.01f;
+// element k of  pooled = [sum/cnt, 0.01*sum, tail]  (epic.py:100-107) straight from the 4 wave partials
+template <int H>
+struct PooledIn {
+  const float* partial;
+  const float* tail;
+  float cnt;
+  __device__ __forceinline__ float operator()(int k) const {
+    if (k >= 2 * H) return tail[k - 2 * H];
+    const int f = k >= H ? k - H : k;
+    const float s = (partial[f] + partial[128 + f]) + (partial[256 + f] + partial[384 + f]);
+    return k >= H ? s * 0.01f : s / cnt;
   }
-  if (tid < T) L.pooled[2 * H + tid] = tail[tid];
-  __syncthreads();
-}
+};
 
 // time vector c = W_t temb of a layer: taken from the per-grid-point table when the caller
 // precomputed it (generation: t is the same for every jet), else a matvec into L.cvec.
@@ -299,7 +347,7 @@ __device__ __forceinline__ const float* time_vec(const float* ctab, int& ci, con
     ++ci;
     return c;
   }
-  matvec<MMB_ACT_NONE, ET, O>(WtT, nullptr, L.temb, L.cvec, nullptr, L.scratch, tid);
+  matvec<MMB_ACT_NONE, ET, O>(WtT, nullptr, L.temb, L.cvec, nullptr, tid);
   return L.cvec;
 }
 
@@ -319,19 +367,23 @@ struct Epic {
     li += 4;
     FE_PROF(L, PF_EPI);
     pool_partials<HT>(x, m, L.partial, wave, lane);
-    build_pooled(H, G, L.gcur, L, tid);
+    AFrag<HT> pre1, pre2;
+    mma_prefetch(pre1, P + l1.wx, lane);               // arrives under the per-jet chain
+    __syncthreads();
     FE_PROF(L, PF_POOL);
-    matvec<MMB_ACT_LRELU, 2 * H + G, H>(P + g1.wt, P + g1.b, L.pooled, L.gh, nullptr, L.scratch, tid);
+    WaveMV<2 * H + G, H>::template run<MMB_ACT_LRELU>(P + g1.wt, P + g1.b, PooledIn<H>{L.partial, L.gcur, L.cnt}, L.gh,
+                                                      nullptr, tid);
     FE_PROF(L, PF_GLOB1);
-    matvec<MMB_ACT_NONE, H, G>(P + g2.wt, P + g2.b, L.gh, L.gnew, L.gcur, L.scratch, tid);   // g' = g + fc_glob2(.)
+    matvec<MMB_ACT_NONE, H, G>(P + g2.wt, P + g2.b, L.gh, L.gnew, L.gcur, tid);      // g' = g + fc_glob2(.)
     FE_PROF(L, PF_GLOB2);
     const float* cv = time_vec<ET, H>(ctab, ci, P + l1.wt, L, tid);
-    matvec<MMB_ACT_NONE, G, H>(P + l1.wg, P + l1.b, L.gnew, L.dvec, nullptr, L.scratch, tid);
+    matvec<MMB_ACT_NONE, G, H>(P + l1.wg, P + l1.b, L.gnew, L.dvec, nullptr, tid);
     FE_PROF(L, PF_DVEC);
     if (tid < G) L.gcur[tid] = lrelu_f(L.gnew[tid]) + (use_skip ? L.gskip[tid] : 0.0f);
     f32x16 lh[HT];
     acc_init<HT>(lh, m, cv, L.dvec, half);
-    mma_x<HT, HT>(lh, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, P + l1.wx, lane);
+    mma_prefetch(pre2, P + l2.wx, lane);               // arrives under the first GEMM
+    mma_x<HT, HT>(lh, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, P + l1.wx, lane, pre1);
     act_tiles<HT, MMB_ACT_LRELU>(lh);
     FE_PROF(L, PF_LOC1);
     // x <- (x + b2) + W2 lh : the residual rides in the accumulator, x's registers ARE the accumulator
@@ -339,7 +391,7 @@ struct Epic {
       ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
         const float4 bv = *reinterpret_cast<const float4*>(P + l2.b + 32 * t + 8 * q + 4 * half);
         x[t][4 * q + 0] += bv.x; x[t][4 * q + 1] += bv.y; x[t][4 * q + 2] += bv.z; x[t][4 * q + 3] += bv.w; }); });
-    mma_x<HT, HT>(x, [&](auto fc) -> const f32x16& { return lh[decltype(fc)::v]; }, P + l2.wx, lane);
+    mma_x<HT, HT>(x, [&](auto fc) -> const f32x16& { return lh[decltype(fc)::v]; }, P + l2.wx, lane, pre2);
     FE_PROF(L, PF_LOC2);
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
       if (use_skip) {
@@ -359,10 +411,12 @@ struct Epic {
     const int lane = tid & 63, half = lane >> 5;
     const LDesc o = D[li];
     li += 1;
+    AFrag<HT> pre;
+    mma_prefetch(pre, P + o.wx, lane);
     const float* cv = time_vec<ET, H>(ctab, ci, P + o.wt, L, tid);
-    matvec<MMB_ACT_NONE, G, H>(P + o.wg, P + o.b, L.gcur, L.dvec, nullptr, L.scratch, tid);
+    matvec<MMB_ACT_NONE, G, H>(P + o.wg, P + o.b, L.gcur, L.dvec, nullptr, tid);
     acc_init<HT>(out, m, cv, L.dvec, half);
-    mma_x<HT, HT>(out, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, P + o.wx, lane);
+    mma_x<HT, HT>(out, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, P + o.wx, lane, pre);
     FE_PROF(L, PF_OUT);
   }
 
@@ -373,19 +427,23 @@ struct Epic {
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const LDesc p0 = D[li], p2 = D[li + 1], q0 = D[li + 2], q2 = D[li + 3];
     li += 4;
+    AFrag<HT> pre0, pre2;
+    mma_prefetch(pre0, P + p0.wx, lane);
+    mma_prefetch(pre2, P + p2.wx, lane);
     const float* cv = time_vec<ET, H>(ctab, ci, P + p0.wt, L, tid);
     f32x16 h[HT];
     acc_init<HT>(h, m, cv, P + p0.b, half);
-    mma_x<1, HT>(h, [&](auto) -> const f32x16& { return xin; }, P + p0.wx, lane);
+    mma_x<1, HT>(h, [&](auto) -> const f32x16& { return xin; }, P + p0.wx, lane, pre0);
     act_tiles<HT, MMB_ACT_GELU>(h);
     acc_init<HT>(x, 0.0f, nullptr, P + p2.b, half);
-    mma_x<HT, HT>(x, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, P + p2.wx, lane);
+    mma_x<HT, HT>(x, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, P + p2.wx, lane, pre2);
     act_tiles<HT, MMB_ACT_GELU>(x);
     FE_PROF(L, PF_PROJ_MMA);
     pool_partials<HT>(x, m, L.partial, wave, lane);
-    build_pooled(H, ET, L.temb, L, tid);               // context = time embedding (dim_context = Et)
-    matvec<MMB_ACT_GELU, 2 * H + ET, H>(P + q0.wt, P + q0.b, L.pooled, L.gh, nullptr, L.scratch, tid);
-    matvec<MMB_ACT_GELU, H, G>(P + q2.wt, P + q2.b, L.gh, L.gcur, nullptr, L.scratch, tid);
+    __syncthreads();                                   // context = time embedding (dim_context = Et)
+    WaveMV<2 * H + ET, H>::template run<MMB_ACT_GELU>(P + q0.wt, P + q0.b, PooledIn<H>{L.partial, L.temb, L.cnt}, L.gh,
+                                                      nullptr, tid);
+    matvec<MMB_ACT_GELU, H, G>(P + q2.wt, P + q2.b, L.gh, L.gcur, nullptr, tid);
     FE_PROF(L, PF_GLOB1);
   }
 };
@@ -475,29 +533,37 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
   if (which != 1) {
     ci = ci_heads;
     const float* cv = time_vec<DM::ET, DM::HB>(A.ctab, ci, A.P + c0.wt, L, tid);
+    AFrag<HBT> pre0;
+    AFrag<1> pre2;
+    mma_prefetch(pre0, A.P + c0.wx, lane);
+    mma_prefetch(pre2, A.P + c2.wx, lane);
     f32x16 h[HBT];
     acc_init<HBT>(h, m, cv, A.P + c0.b, half);
     mma_x<HFT, HBT>(h, [&](auto fc) -> f32x16 {
       constexpr int t = decltype(fc)::v;
-      if constexpr (t < HBT) return f[t]; else return fetch_tile(S, t - HBT, tid); }, A.P + c0.wx, lane);
+      if constexpr (t < HBT) return f[t]; else return fetch_tile(S, t - HBT, tid); }, A.P + c0.wx, lane, pre0);
     act_tiles<HBT, MMB_ACT_GELU>(h);
     f32x16 o[1];
     acc_init<1>(o, 0.0f, nullptr, A.P + c2.b, half);
-    mma_x<HBT, 1>(o, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, A.P + c2.wx, lane);
+    mma_x<HBT, 1>(o, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, A.P + c2.wx, lane, pre2);
     hc = o[0];
   }
   if (which != 0) {
     ci = ci_heads + 1;
     const float* cv = time_vec<DM::ET, DM::HB>(A.ctab, ci, A.P + d0.wt, L, tid);
+    AFrag<HBT> pre0;
+    AFrag<1> pre2;
+    mma_prefetch(pre0, A.P + d0.wx, lane);
+    mma_prefetch(pre2, A.P + d2.wx, lane);
     f32x16 h[HBT];
     acc_init<HBT>(h, m, cv, A.P + d0.b, half);
     mma_x<HFT, HBT>(h, [&](auto fc) -> f32x16 {
       constexpr int t = decltype(fc)::v;
-      if constexpr (t < HBT) return f[HBT + t]; else return fetch_tile(S, t, tid); }, A.P + d0.wx, lane);
+      if constexpr (t < HBT) return f[HBT + t]; else return fetch_tile(S, t, tid); }, A.P + d0.wx, lane, pre0);
     act_tiles<HBT, MMB_ACT_GELU>(h);
     f32x16 o[1];
     acc_init<1>(o, 0.0f, nullptr, A.P + d2.b, half);
-    mma_x<HBT, 1>(o, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, A.P + d2.wx, lane);
+    mma_x<HBT, 1>(o, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, A.P + d2.wx, lane, pre2);
     hd = o[0];
   }
   FE_PROF(L, PF_HEAD);

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmb_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("MMB_LIB_NAME", "libmmb_hip.so"))   # developer builds: other name
 
 c_f32p = C.c_void_p     # device pointers travel as plain addresses
 c_i64p = C.c_void_p

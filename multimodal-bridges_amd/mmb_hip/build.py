@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
-LIB = os.path.join(HERE, "libmmb_hip.so")
+LIB = os.path.join(HERE, os.environ.get("MMB_LIB_NAME", "libmmb_hip.so"))      # developer builds: other name
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"] + os.environ.get("MMB_EXTRA_FLAGS", "").split()
@@ -29,9 +29,10 @@ def build(force=False, verbose=True):
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "..", "..", "include", "*.h"))
     objs = []
     procs = []
-    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    objdir = os.path.join(CSRC, "build" + os.environ.get("MMB_OBJ_SUFFIX", ""))
+    os.makedirs(objdir, exist_ok=True)
     for s in srcs:
-        o = os.path.join(CSRC, "build", os.path.basename(s)[:-4] + ".o")
+        o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
             cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]

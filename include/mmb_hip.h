@@ -291,6 +291,27 @@ int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, cons
                             uint64_t seed, uint64_t offset,
                             int em, float em_sigma, const float* delta_w, void* stream);
 
+/* UniModalEPiC (discrete-only model): MultiModalBridgeMatching.forward with
+ * encoders/multimodal_epic.py:44-64 (+ embedder.py:74-80, epic.py:71-98) for one jet per workgroup.
+ * The projection sees cat[t, t, trunc(k_emb*mask)]; both time blocks are summed on the host.
+ * variant 0: Et128 Ed128 H128 G16 (configs/S2_discrete.yaml); variant 1: Et16 Ed16 H32 G8.
+ * N <= 128, V = 8.  head_d: (B,N,8) logits. */
+int mmb_fused_uni_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
+                          int num_blocks, int use_skip, int off_table,
+                          const float* maskf, const int32_t* counts, const int64_t* k,
+                          const float* temb, int64_t temb_stride, float* head_d, void* stream);
+
+/* simulate_dynamics (multimodal_bridge_matching.py:227-259) of the discrete-only model in ONE
+ * launch: per grid point forward -> telegraph rates -> tau-leap jump; final k = argmax of the last
+ * rates.  Arguments as mmb_fused_epic_generate. */
+int mmb_fused_uni_generate(int variant, int B, int N, const float* packed, const int32_t* desc,
+                           int num_blocks, int use_skip, int off_table,
+                           const float* maskf, const int32_t* counts, int64_t* k,
+                           int steps, const float* times, const float* temb_steps,
+                           const float* ctab_steps, int n_ctab, float dt,
+                           int thermo_kind, float gamma, const float* delta_n,
+                           uint64_t seed, uint64_t offset, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

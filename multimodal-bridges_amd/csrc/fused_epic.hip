@@ -404,24 +404,26 @@ struct Epic {
     FE_PROF(L, PF_EPI);
   }
 
-  // output layer: wn Linear on cat[t, x, g] (epic.py:93-96)
-  static __device__ __forceinline__ void output(f32x16 (&out)[HT], const f32x16 (&x)[HT],
+  // output layer: wn Linear on cat[t, x, g] (epic.py:93-96); OTO output tiles, OW = true output width
+  template <int OTO, int OW>
+  static __device__ __forceinline__ void output(f32x16 (&out)[OTO], const f32x16 (&x)[HT],
                                                 const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
                                                 float m, int tid, const float* ctab, int& ci) {
     const int lane = tid & 63, half = lane >> 5;
     const LDesc o = D[li];
     li += 1;
-    AFrag<HT> pre;
+    AFrag<OTO> pre;
     mma_prefetch(pre, P + o.wx, lane);
-    const float* cv = time_vec<ET, H>(ctab, ci, P + o.wt, L, tid);
-    matvec<MMB_ACT_NONE, G, H>(P + o.wg, P + o.b, L.gcur, L.dvec, nullptr, tid);
-    acc_init<HT>(out, m, cv, L.dvec, half);
-    mma_x<HT, HT>(out, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, P + o.wx, lane, pre);
+    const float* cv = time_vec<ET, OW>(ctab, ci, P + o.wt, L, tid);
+    matvec<MMB_ACT_NONE, G, OW>(P + o.wg, P + o.b, L.gcur, L.dvec, nullptr, tid);
+    acc_init<OTO>(out, m, cv, L.dvec, half);
+    mma_x<HT, OTO>(out, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, P + o.wx, lane, pre);
     FE_PROF(L, PF_OUT);
   }
 
-  // EPiCProjection (epic.py:145-159) from ONE padded input tile
-  static __device__ __forceinline__ void project(f32x16 (&x)[HT], const f32x16& xin,
+  // EPiCProjection (epic.py:145-159) from KIN padded input tiles delivered by xin(IF<t>)
+  template <int KIN, typename InFn>
+  static __device__ __forceinline__ void project(f32x16 (&x)[HT], InFn&& xin,
                                                  const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
                                                  float m, int tid, const float* ctab, int& ci) {
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5;
@@ -433,7 +435,7 @@ struct Epic {
     const float* cv = time_vec<ET, H>(ctab, ci, P + p0.wt, L, tid);
     f32x16 h[HT];
     acc_init<HT>(h, m, cv, P + p0.b, half);
-    mma_x<1, HT>(h, [&](auto) -> const f32x16& { return xin; }, P + p0.wx, lane, pre0);
+    mma_x<KIN, HT>(h, xin, P + p0.wx, lane, pre0);
     act_tiles<HT, MMB_ACT_GELU>(h);
     acc_init<HT>(x, 0.0f, nullptr, P + p2.b, half);
     mma_x<HT, HT>(x, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, P + p2.wx, lane, pre2);
@@ -446,6 +448,23 @@ struct Epic {
     matvec<MMB_ACT_GELU, H, G>(P + q2.wt, P + q2.b, L.gh, L.gcur, nullptr, tid);
     FE_PROF(L, PF_GLOB1);
   }
+};
+
+// arguments of the single-launch generation loops
+struct GenArgs {
+  int steps;
+  const float* times;        // (steps) grid points (host linspace, fp32)
+  const float* temb_steps;   // (steps, ET) time embedding per grid point (identical for every jet)
+  const float* ctab_steps;   // (steps, n_ctab, 128) precomputed W_t temb of every time-consuming layer
+  int n_ctab;
+  float dt;
+  int thermo_kind;
+  float thermo_c;            // fp32(-V*gamma)
+  const float* delta_n;      // (steps,B,N,V) injected Poisson counts or NULL -> Philox
+  uint64_t seed, offset;
+  int em;                    // 1: Euler-Maruyama  x += dt v + sigma sqrt(t(1-t)) dW  (solvers.py:27-33, no sqrt(dt))
+  float em_sigma;
+  const float* delta_w;      // (steps,B,N,DC) injected Wiener increments or NULL -> Philox/Box-Muller
 };
 
 // ------------------------------------------------------------------ model dimensions ----
@@ -505,14 +524,15 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
   ffor<2>([&](auto bc) {
     constexpr int br = decltype(bc)::v;
     f32x16 x[HBT], sk[HBT], out[HBT];
-    Epic<HBT, DM::ET, DM::GB>::project(x, br == 0 ? tc : td, A.P, A.D, li, L, m, tid, A.ctab, ci);
+    Epic<HBT, DM::ET, DM::GB>::template project<1>(x, [&](auto) -> const f32x16& { return br == 0 ? tc : td; }, A.P,
+                                                   A.D, li, L, m, tid, A.ctab, ci);
     if (tid < DM::GB) L.gskip[tid] = L.gcur[tid];
     ffor<HBT>([&](auto t) { sk[decltype(t)::v] = x[decltype(t)::v]; });
     __syncthreads();
     for (int i = 0; i < A.nb_branch; ++i)
       Epic<HBT, DM::ET, DM::GB>::layer(x, [&](auto t) -> const f32x16& { return sk[decltype(t)::v]; },
                                        A.use_skip != 0, A.P, A.D, li, L, m, tid, A.ctab, ci);
-    Epic<HBT, DM::ET, DM::GB>::output(out, x, A.P, A.D, li, L, m, tid, A.ctab, ci);
+    Epic<HBT, DM::ET, DM::GB>::template output<HBT, DM::HB>(out, x, A.P, A.D, li, L, m, tid, A.ctab, ci);
     ffor<HBT>([&](auto t) { park_tile(S, br * HBT + decltype(t)::v, out[decltype(t)::v], tid); });
     if (tid < DM::GB) L.gcat[br * DM::GB + tid] = L.gcur[tid];
     __syncthreads();
@@ -525,7 +545,7 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
   for (int i = 0; i < A.nb_fused_exec; ++i)
     Epic<HFT, DM::ET, DM::GF>::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, decltype(t)::v, tid); },
                                      A.use_skip != 0, A.P, A.D, li, L, m, tid, A.ctab, ci);
-  Epic<HFT, DM::ET, DM::GF>::output(f, x, A.P, A.D, li, L, m, tid, A.ctab, ci);
+  Epic<HFT, DM::ET, DM::GF>::template output<HFT, 2 * DM::HB>(f, x, A.P, A.D, li, L, m, tid, A.ctab, ci);
   // ---- heads (multimodal_epic.py:187-189): cat[t, f_i, h_i] -> GELU -> out
   const LDesc c0 = A.D[li], c2 = A.D[li + 1], d0 = A.D[li + 2], d2 = A.D[li + 3];
   FE_PROF(L, PF_EPI);
@@ -639,23 +659,61 @@ fused_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64_t* __
 }
 
 // ---- the whole generation loop (multimodal_bridge_matching.py:227-259) --------------------
-struct GenArgs {
-  int steps;
-  const float* times;        // (steps) grid points (host linspace, fp32)
-  const float* temb_steps;   // (steps, ET) time embedding per grid point (identical for every jet)
-  const float* ctab_steps;   // (steps, n_ctab, 128) precomputed W_t temb of every time-consuming layer
-  int n_ctab;
-  float dt;
-  int thermo_kind;
-  float thermo_c;            // fp32(-V*gamma)
-  const float* delta_n;      // (steps,B,N,V) injected Poisson counts or NULL -> Philox
-  uint64_t seed, offset;
-  int em;                    // 1: Euler-Maruyama  x += dt v + sigma sqrt(t(1-t)) dW  (solvers.py:27-33, no sqrt(dt))
-  float em_sigma;
-  const float* delta_w;      // (steps,B,N,DC) injected Wiener increments or NULL -> Philox/Box-Muller
-};
-
 __device__ __forceinline__ float thermo_w_f(int kind, float c, float t0, float t1) { return thermo_w(kind, c, t0, t1); }
+
+// telegraph rates (bridges.py:137-163) + tau-leap jump / final argmax (solvers.py:59-81, matching.py:253-255)
+// on the V=8 logits of one particle; shared by the multimodal and the discrete-only loops.
+__device__ __forceinline__ int jump_step(float (&r)[8], int kp, float tt, const GenArgs& Gn, bool last, bool valid,
+                                         int B, int N, int b, int p, int s, int64_t gp) {
+  constexpr int V = 8;
+  const float w = thermo_w(Gn.thermo_kind, Gn.thermo_c, tt, 1.0f);
+  const float Bc = (w * (float)V) / (1.0f - w);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int v = 0; v < V; ++v) mx = fmaxf(mx, r[v]);
+  float sum = 0.0f;
+#pragma unroll
+  for (int v = 0; v < V; ++v) { r[v] = expf(r[v] - mx); sum += r[v]; }
+  float qk = 0.0f;
+#pragma unroll
+  for (int v = 0; v < V; ++v) { r[v] = r[v] / sum; qk = (v == kp) ? r[v] : qk; }
+#pragma unroll
+  for (int v = 0; v < V; ++v) r[v] = 1.0f + Bc * r[v] + w * qk;
+  if (last) {
+    int best = 0;
+    float bv = r[0];
+#pragma unroll
+    for (int v = 1; v < V; ++v) if (r[v] > bv) { bv = r[v]; best = v; }
+    return best;
+  }
+  if (Gn.delta_n != nullptr) {
+    int knew = kp;
+    if (valid) {
+      const float* dn = Gn.delta_n + (((int64_t)s * B + b) * N + p) * V;
+      float tot = 0.0f, net = 0.0f;
+#pragma unroll
+      for (int v = 0; v < V; ++v) { const float d = dn[v]; tot += d; net += d * (float)(v - kp); }
+      const int64_t ok = ((int64_t)tot <= 1) ? 1 : 0;
+      int64_t moved = (int64_t)kp + (int64_t)net * ok;
+      moved %= V;
+      if (moved < 0) moved += V;
+      knew = (int)moved;
+    }
+    return knew;
+  }
+  uint32_t q[4];
+  philox4(Gn.seed, Gn.offset + (uint64_t)s, (uint64_t)gp, 0xC001u, q);
+  const float u = u01(q[0]);
+  float Lam = 0.0f;
+#pragma unroll
+  for (int v = 0; v < V; ++v) Lam += r[v] * Gn.dt;
+  const float e = expf(-Lam);
+  float acc = 0.0f;
+  int hit = -1;
+#pragma unroll
+  for (int v = 0; v < V; ++v) { acc += r[v] * Gn.dt * e; if (hit < 0 && u < acc) hit = v; }
+  return hit >= 0 ? hit : kp;
+}
 
 template <class DM>
 __global__ void __launch_bounds__(FE_THREADS, 2)
@@ -719,55 +777,7 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
       forward_jet<DM>(A, L, S, xp, kp, m, 1, hc, hd, tid);
       float r[V];
       gather_logits<DM>(hd, r, lane);
-      {
-        const float w = thermo_w_f(Gn.thermo_kind, Gn.thermo_c, tt, 1.0f);
-        const float Bc = (w * (float)V) / (1.0f - w);
-        float mx = -INFINITY;
-#pragma unroll
-        for (int v = 0; v < V; ++v) mx = fmaxf(mx, r[v]);
-        float sum = 0.0f;
-#pragma unroll
-        for (int v = 0; v < V; ++v) { r[v] = expf(r[v] - mx); sum += r[v]; }
-        float qk = 0.0f;
-#pragma unroll
-        for (int v = 0; v < V; ++v) { r[v] = r[v] / sum; qk = (v == kp) ? r[v] : qk; }
-#pragma unroll
-        for (int v = 0; v < V; ++v) r[v] = 1.0f + Bc * r[v] + w * qk;
-      }
-      if (s == Gn.steps - 1) {                           // final state: argmax of the last rates (:253-255)
-        int best = 0;
-        float bv = r[0];
-#pragma unroll
-        for (int v = 1; v < V; ++v) if (r[v] > bv) { bv = r[v]; best = v; }
-        kp = best;
-      } else if (Gn.delta_n != nullptr) {
-        int knew = kp;
-        if (valid) {
-          const float* dn = Gn.delta_n + (((int64_t)s * A.B + b) * A.N + p) * V;
-          float tot = 0.0f, net = 0.0f;
-#pragma unroll
-          for (int v = 0; v < V; ++v) { const float d = dn[v]; tot += d; net += d * (float)(v - kp); }
-          const int64_t ok = ((int64_t)tot <= 1) ? 1 : 0;
-          int64_t moved = (int64_t)kp + (int64_t)net * ok;
-          moved %= V;
-          if (moved < 0) moved += V;
-          knew = (int)moved;
-        }
-        kp = knew;
-      } else {
-        uint32_t q[4];
-        philox4(Gn.seed, Gn.offset + (uint64_t)s, (uint64_t)gp, 0xC001u, q);
-        const float u = u01(q[0]);
-        float Lam = 0.0f;
-#pragma unroll
-        for (int v = 0; v < V; ++v) Lam += r[v] * Gn.dt;
-        const float e = expf(-Lam);
-        float acc = 0.0f;
-        int hit = -1;
-#pragma unroll
-        for (int v = 0; v < V; ++v) { acc += r[v] * Gn.dt * e; if (hit < 0 && u < acc) hit = v; }
-        if (hit >= 0) kp = hit;
-      }
+      kp = jump_step(r, kp, tt, Gn, s == Gn.steps - 1, valid, A.B, A.N, b, p, s, gp);
     }
     if (valid && half == 0) {
 #pragma unroll
@@ -776,6 +786,137 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
     }
   }
 }
+
+// ==================================================================== UniModalEPiC ====
+// Discrete-only model (multimodal_epic.py:44-64): ONE EPiC encoder with projection on
+// cat[t, t, trunc(k_emb*mask)] (the time embedding enters twice: multimodal_epic.py:47-54 +
+// epic.py:155 -- both column blocks are summed into one time vector on the host), whose output
+// layer emits the V logits directly (no heads).
+template <int ET_, int ED_, int H_, int G_, int V_>
+struct UniDims {
+  static constexpr int ET = ET_, ED = ED_, H = H_, G = G_, V = V_;
+  static constexpr int HT = H / 32;
+  static constexpr int EDT = (ED + 31) / 32;      // input tiles
+  static constexpr int EDP = 32 * EDT;            // padded embedding width
+};
+
+template <class DM>
+__device__ __forceinline__ void forward_uni(const FusedArgs& A, Lds& L, float4* S, const float* tab, int kp, float m,
+                                            f32x16& hd, int tid) {
+  constexpr int HT = DM::HT;
+  const int lane = tid & 63, half = lane >> 5;
+  int li = 0, ci = 0;
+  FE_PROF(L, PF_STEP);
+  f32x16 td[DM::EDT];
+  ffor<DM::EDT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+    ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
+      const float4 e = *reinterpret_cast<const float4*>(tab + kp * DM::EDP + 32 * t + 8 * q + 4 * half);
+      td[t][4 * q + 0] = truncf(e.x * m); td[t][4 * q + 1] = truncf(e.y * m);      // quirk Q1
+      td[t][4 * q + 2] = truncf(e.z * m); td[t][4 * q + 3] = truncf(e.w * m); }); });
+  FE_PROF(L, PF_EMBED);
+  f32x16 x[HT];
+  Epic<HT, DM::ET, DM::G>::template project<DM::EDT>(x, [&](auto fc) -> const f32x16& { return td[decltype(fc)::v]; },
+                                                    A.P, A.D, li, L, m, tid, A.ctab, ci);
+  if (tid < DM::G) L.gskip[tid] = L.gcur[tid];
+  ffor<HT>([&](auto t) { park_tile(S, decltype(t)::v, x[decltype(t)::v], tid); });
+  __syncthreads();
+  for (int i = 0; i < A.nb_branch; ++i)
+    Epic<HT, DM::ET, DM::G>::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, decltype(t)::v, tid); },
+                                   A.use_skip != 0, A.P, A.D, li, L, m, tid, A.ctab, ci);
+  f32x16 o[1];
+  Epic<HT, DM::ET, DM::G>::template output<1, DM::V>(o, x, A.P, A.D, li, L, m, tid, A.ctab, ci);
+  hd = o[0];
+}
+
+template <class DM>
+__device__ __forceinline__ void load_table_uni(const FusedArgs& A, float* tab, int tid) {
+  for (int i = tid; i < DM::V * DM::EDP; i += FE_THREADS) {
+    const int v = i / DM::EDP, e = i % DM::EDP;
+    tab[i] = e < DM::ED ? A.P[A.emb_table + v * DM::ED + e] : 0.0f;
+  }
+}
+
+// gather V=8 logits of this lane's particle from an output tile (features 0..3 half 0, 4..7 half 1)
+__device__ __forceinline__ void gather8(const f32x16& hd, float (&lg)[8], int lane) {
+  const int half = lane >> 5;
+  float mine[4] = {hd[0], hd[1], hd[2], hd[3]};
+  float other[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) other[i] = __shfl_xor(mine[i], 32, 64);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    lg[i] = half == 0 ? mine[i] : other[i];
+    lg[4 + i] = half == 0 ? other[i] : mine[i];
+  }
+}
+
+template <class DM>
+__global__ void __launch_bounds__(FE_THREADS, 2)
+fused_uni_forward_kernel(FusedArgs A, const int64_t* __restrict__ k, const float* __restrict__ temb,
+                         int64_t temb_stride, float* __restrict__ head_d) {
+  static_assert(DM::V == 8, "fused path is instantiated for vocab_size 8");
+  __shared__ Lds L;
+  __shared__ float4 S[DM::HT * 4 * FE_THREADS];
+  __shared__ __attribute__((aligned(16))) float tab[DM::V * DM::EDP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  load_table_uni<DM>(A, tab, tid);
+  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+    __syncthreads();
+    if (tid < DM::ET) L.temb[tid] = temb[(int64_t)b * temb_stride + tid];
+    if (tid == 0) L.cnt = (float)A.counts[b];
+    const int p = 32 * wave + (lane & 31);
+    const bool valid = p < A.N;
+    const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
+    const float m = valid ? A.maskf[gp] : 0.0f;
+    const int kp = valid ? (int)k[gp] : 0;
+    __syncthreads();
+    f32x16 hd;
+    forward_uni<DM>(A, L, S, tab, kp, m, hd, tid);
+    float lg[8];
+    gather8(hd, lg, lane);
+    if (valid && half == 0) {
+#pragma unroll
+      for (int v = 0; v < 8; ++v) head_d[gp * 8 + v] = lg[v];
+    }
+  }
+}
+
+template <class DM>
+__global__ void __launch_bounds__(FE_THREADS, 2)
+fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
+  __shared__ Lds L;
+  __shared__ float4 S[DM::HT * 4 * FE_THREADS];
+  __shared__ __attribute__((aligned(16))) float tab[DM::V * DM::EDP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+#ifdef MMB_FE_PROF
+  if (tid == 0) L.tlast = clock64();
+#endif
+  load_table_uni<DM>(A, tab, tid);
+  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+    __syncthreads();
+    if (tid == 0) L.cnt = (float)A.counts[b];
+    const int p = 32 * wave + (lane & 31);
+    const bool valid = p < A.N;
+    const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
+    const float m = valid ? A.maskf[gp] : 0.0f;
+    int kp = valid ? (int)k[gp] : 0;
+    for (int s = 0; s < Gn.steps; ++s) {
+      __syncthreads();
+      if (tid < DM::ET) L.temb[tid] = Gn.temb_steps[(int64_t)s * DM::ET + tid];
+      __syncthreads();
+      A.ctab = Gn.ctab_steps ? Gn.ctab_steps + (int64_t)s * Gn.n_ctab * 128 : nullptr;
+      f32x16 hd;
+      forward_uni<DM>(A, L, S, tab, kp, m, hd, tid);
+      float r[8];
+      gather8(hd, r, lane);
+      kp = jump_step(r, kp, Gn.times[s], Gn, s == Gn.steps - 1, valid, A.B, A.N, b, p, s, gp);
+    }
+    if (valid && half == 0) k[gp] = kp;
+  }
+}
+
+typedef UniDims<128, 128, 128, 16, 8> UniS2;         // configs/S2_discrete.yaml
+typedef UniDims<16, 16, 32, 8, 8> UniMid;            // the uni_mid golden
 
 typedef Dims<32, 16, 16, 64, 16, 3, 8> DimsS3;       // configs/S3_multimodal.yaml
 typedef Dims<16, 8, 8, 32, 8, 3, 8> DimsMid;         // the mm_mid golden / small models
@@ -814,6 +955,50 @@ extern "C" int mmb_fused_epic_forward(int variant, int B, int N, const float* pa
     hipLaunchKernelGGL(fused_forward_kernel<DimsMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k, temb,
                        temb_stride, which, head_c, head_d);
   return check_launch("mmb_fused_epic_forward");
+}
+
+// variant: 0 = S2 widths (Et128 Ed128 H128 G16), 1 = Et16 Ed16 H32 G8
+extern "C" int mmb_fused_uni_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
+                                     int num_blocks, int use_skip, int off_table, const float* maskf,
+                                     const int32_t* counts, const int64_t* k, const float* temb, int64_t temb_stride,
+                                     float* head_d, void* stream) {
+  int rc = check_fused("mmb_fused_uni_forward", B, N, packed, desc, maskf, counts);
+  if (rc) return rc;
+  MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_uni_forward: unknown variant %d", variant);
+  MMB_REQUIRE(k && temb && head_d, "mmb_fused_uni_forward: NULL state");
+  FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), num_blocks, 0, use_skip, 0, 0, off_table, B, N,
+              maskf, counts};
+  const int grid = B < 4096 ? B : 4096;
+  if (variant == 0)
+    hipLaunchKernelGGL(fused_uni_forward_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k, temb,
+                       temb_stride, head_d);
+  else
+    hipLaunchKernelGGL(fused_uni_forward_kernel<UniMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k, temb,
+                       temb_stride, head_d);
+  return check_launch("mmb_fused_uni_forward");
+}
+
+extern "C" int mmb_fused_uni_generate(int variant, int B, int N, const float* packed, const int32_t* desc,
+                                      int num_blocks, int use_skip, int off_table, const float* maskf,
+                                      const int32_t* counts, int64_t* k, int steps, const float* times,
+                                      const float* temb_steps, const float* ctab_steps, int n_ctab, float dt,
+                                      int thermo_kind, float gamma, const float* delta_n, uint64_t seed,
+                                      uint64_t offset, void* stream) {
+  int rc = check_fused("mmb_fused_uni_generate", B, N, packed, desc, maskf, counts);
+  if (rc) return rc;
+  MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_uni_generate: unknown variant %d", variant);
+  MMB_REQUIRE(k && times && temb_steps && steps > 0, "mmb_fused_uni_generate: NULL state / steps");
+  MMB_REQUIRE(thermo_kind >= 0 && thermo_kind <= 4, "mmb_fused_uni_generate: bad thermostat");
+  FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), num_blocks, 0, use_skip, 0, 0, off_table, B, N,
+              maskf, counts};
+  GenArgs Gn{steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, (float)(-(double)8 * (double)gamma), delta_n,
+             seed, offset, 0, 0.0f, nullptr};
+  const int grid = B < 4096 ? B : 4096;
+  if (variant == 0)
+    hipLaunchKernelGGL(fused_uni_generate_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k);
+  else
+    hipLaunchKernelGGL(fused_uni_generate_kernel<UniMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k);
+  return check_launch("mmb_fused_uni_generate");
 }
 
 #ifdef MMB_FE_PROF

@@ -23,6 +23,29 @@ VARIANTS = {  # (Et, Ec, Ed, Hb, Gb) -> variant id (fused_epic.hip: DimsS3 / Dim
 }
 
 
+UNI_VARIANTS = {  # (Et, Ed, H, G) -> variant id (fused_epic.hip: UniS2 / UniMid)
+    (128, 128, 128, 16): 0,
+    (16, 16, 32, 8): 1,
+}
+MAX_TIME_LAYERS = 64
+
+
+def eligible_uni(model):
+    """Variant id if the model is a discrete-only UniModalEPiC of a compiled width set."""
+    cfg = model.config
+    e, d = cfg.encoder, cfg.data
+    if e.name != "UniModalEPiC" or d.modality != "discrete":
+        return None
+    if d.vocab_size != 8 or d.dim_discrete != 1 or (d.max_num_particles or 0) > 128:
+        return None
+    if e.dim_emb_context_continuous or e.dim_emb_context_discrete:
+        return None
+    hl, hg = e.dim_hidden_local, e.dim_hidden_glob
+    if isinstance(hl, (list, tuple)) or isinstance(hg, (list, tuple)):
+        return None
+    return UNI_VARIANTS.get((e.dim_emb_time, e.dim_emb_discrete, hl, hg))
+
+
 def eligible(model):
     """Variant id if the model is a branched+fused MultiModalEPiC of a compiled width set."""
     cfg = model.config
@@ -49,6 +72,7 @@ class _Packer:
     def __init__(self, device):
         self.chunks, self.n, self.desc, self.device = [], 0, [], device
         self.time_parts = []          # W[:, :Et] of every layer that consumes the time embedding, kernel order
+        self.mfma_flops = []          # 2*K_pad*O_pad of every per-particle layer (what the MFMAs execute)
 
     def add(self, t):
         t = t.contiguous().reshape(-1).float()
@@ -76,13 +100,22 @@ class _Packer:
         bp[:O] = b
         return self.add(bp)
 
-    def particle_layer(self, lin, n_t, n_x, n_g):
-        """columns = [t (n_t) | x (n_x) | g (n_g)]"""
+    def particle_layer(self, lin, n_t, n_x, n_g, time_twice=False):
+        """columns = [t (n_t) | x (n_x) | g (n_g)]; time_twice: [t | t | x | g], both time blocks act
+        on the same embedding and are summed into one"""
         W = lin.weight()
-        wt = self.add(W[:, :n_t].t()) if n_t else -1
+        Wt = None
         if n_t:
-            self.time_parts.append(W[:, :n_t])
-        wx = self.add(self.pack_x(W[:, n_t:n_t + n_x]))
+            Wt = W[:, :n_t]
+            if time_twice:
+                Wt = (Wt + W[:, n_t:2 * n_t]).contiguous()
+                W = W[:, n_t:]
+        wt = self.add(Wt.t()) if n_t else -1
+        if n_t:
+            self.time_parts.append(Wt)
+        packed_x = self.pack_x(W[:, n_t:n_t + n_x])
+        self.mfma_flops.append(2 * packed_x.numel())
+        wx = self.add(packed_x)
         wg = self.add(W[:, n_t + n_x:].t()) if n_g else -1
         self.desc.append([wx, wt, wg, self.bias(lin.bias.detach())])
 
@@ -91,8 +124,39 @@ class _Packer:
         self.desc.append([-1, self.add(W.t()), -1, self.add(lin.bias.detach())])
 
 
+def pack_uni(model, variant):
+    cfg = model.config
+    enc, emb = model.encoder.epic, model.embedder
+    Et, Ed = cfg.encoder.dim_emb_time, cfg.encoder.dim_emb_discrete
+    H, G = cfg.encoder.dim_hidden_local, cfg.encoder.dim_hidden_glob
+    dev = next(model.parameters()).device
+    pk = _Packer(dev)
+    pr = enc.epic_proj
+    pk.particle_layer(pr.mlp_local["0"], Et, Ed, 0, time_twice=True)
+    pk.particle_layer(pr.mlp_local["2"], 0, H, 0)
+    pk.jet_layer(pr.mlp_global["0"])
+    pk.jet_layer(pr.mlp_global["2"])
+    for i in range(enc.num_blocks):
+        ly = enc.epic_layers[i]
+        pk.jet_layer(ly.fc_glob1)
+        pk.jet_layer(ly.fc_glob2)
+        pk.particle_layer(ly.fc_loc1, Et, H, G)
+        pk.particle_layer(ly.fc_loc2, 0, H, 0)
+    pk.particle_layer(enc.output_layer, Et, H, G)
+    off_table = pk.add(emb.discrete_embedding.table())
+    packed = torch.cat(pk.chunks)
+    desc = torch.tensor(pk.desc, dtype=torch.int32, device=dev).reshape(-1)
+    return {"kind": "uni", "packed": packed, "desc": desc, "variant": variant, "num_blocks": enc.num_blocks,
+            "use_skip": int(bool(cfg.encoder.skip_connection)), "off_table": off_table, "time_parts": pk.time_parts,
+            "mfma_flops_per_forward": sum(pk.mfma_flops)}
+
+
 def pack_model(model):
-    """-> dict(packed, desc, variant, nb_branch, nb_fused_exec, use_skip, off_cw, off_cb, off_table)."""
+    """-> dict(kind, packed, desc, variant, ...) for the fused kernels, or None when the architecture
+    is not one of the compiled width sets."""
+    uv = eligible_uni(model)
+    if uv is not None:
+        return pack_uni(model, uv)
     variant = eligible(model)
     if variant is None:
         return None
@@ -133,9 +197,11 @@ def pack_model(model):
     off_table = pk.add(emb.discrete_embedding.table())
     packed = torch.cat(pk.chunks)
     desc = torch.tensor(pk.desc, dtype=torch.int32, device=dev).reshape(-1)
-    return {"packed": packed, "desc": desc, "variant": variant, "nb_branch": enc.continuous_encoder.num_blocks,
+    return {"kind": "multi", "packed": packed, "desc": desc, "variant": variant, "nb_branch": enc.continuous_encoder.num_blocks,
             "nb_fused_exec": fe.num_blocks, "use_skip": int(bool(cfg.encoder.skip_connection)),
-            "off_cw": off_cw, "off_cb": off_cb, "off_table": off_table, "time_parts": pk.time_parts}
+            "off_cw": off_cw, "off_cb": off_cb, "off_table": off_table, "time_parts": pk.time_parts,
+            # a generation forward evaluates ONE head (the last four particle layers are head_c.0/.2, head_d.0/.2)
+            "mfma_flops_per_forward": sum(pk.mfma_flops) - sum(pk.mfma_flops[-2:])}
 
 
 def time_vector_table(pack, temb_steps):
@@ -177,6 +243,27 @@ def generate(pack, mi, x, k, times, temb_steps, dt, thermo_kind, gamma, delta_n=
          i32(mi.counts), f32(x, "x"), i64(k, "k"), times.numel(), f32(times, "times"), f32(temb_steps, "temb_steps"),
          f32(ctab, "ctab"), n_ctab, _fl(dt), thermo_kind, _fl(gamma), f32(delta_n, "delta_n"), seed, offset,
          0 if em_sigma is None else 1, _fl(0.0 if em_sigma is None else em_sigma), f32(delta_w, "delta_w"), stream())
+
+
+def forward_uni(pack, mi, k, temb, temb_stride=None):
+    """-> logits (B,N,8) of the discrete-only model"""
+    B, N = mi.B, mi.N
+    hd = torch.empty(B, N, 8, dtype=torch.float32, device=k.device)
+    stride = temb.stride(0) if temb_stride is None else temb_stride
+    call("mmb_fused_uni_forward", pack["variant"], B, N, f32(pack["packed"]), i32(pack["desc"]), pack["num_blocks"],
+         pack["use_skip"], pack["off_table"], f32(mi.maskf), i32(mi.counts), i64(k, "k"), f32(temb, "temb"), stride,
+         f32(hd), stream())
+    return hd
+
+
+def generate_uni(pack, mi, k, times, temb_steps, dt, thermo_kind, gamma, delta_n=None, seed=0, offset=0, ctab=None):
+    """In-place discrete-only generation loop on k (B,N,1)."""
+    B, N = mi.B, mi.N
+    n_ctab = 0 if ctab is None else ctab.shape[1]
+    call("mmb_fused_uni_generate", pack["variant"], B, N, f32(pack["packed"]), i32(pack["desc"]), pack["num_blocks"],
+         pack["use_skip"], pack["off_table"], f32(mi.maskf), i32(mi.counts), i64(k, "k"), times.numel(),
+         f32(times, "times"), f32(temb_steps, "temb_steps"), f32(ctab, "ctab"), n_ctab, _fl(dt), thermo_kind,
+         _fl(gamma), f32(delta_n, "delta_n"), seed, offset, stream())
 
 
 def algorithmic_flops_per_particle(model):

@@ -134,6 +134,13 @@ class MultiModalBridgeMatching(nn.Module):
             self._fused_cache = (ver, fused_epic.pack_model(self))
         return self._fused_cache[1]
 
+    @staticmethod
+    def _pack_serves(pack, state):
+        """multi: hybrid states; uni: discrete-only states"""
+        if pack["kind"] == "uni":
+            return state.has_discrete and not state.has_continuous
+        return state.has_continuous and state.has_discrete
+
     def _time_embedding(self, t):
         te = self.embedder.time_embedding
         return ops.time_embed(t, te[0].W.detach(), te[1].weight.detach(), te[1].bias.detach())
@@ -149,7 +156,9 @@ class MultiModalBridgeMatching(nn.Module):
         t = getattr(state, "_t_scalar", None)
         time = state.time if t is None else t
         inference = self._tape is None and (not self.training or not self.config.encoder.dropout)
-        pack = self._fused_pack() if (inference and state.has_continuous and state.has_discrete) else None
+        pack = self._fused_pack() if inference else None
+        if pack is not None and not self._pack_serves(pack, state):
+            pack = None
         if pack is not None:
             B = mi.B
             if t is None:
@@ -159,6 +168,9 @@ class MultiModalBridgeMatching(nn.Module):
             else:
                 temb = self._time_embedding(torch.full((1,), float(t), device=state.mask.device))
                 stride = 0
+            if pack["kind"] == "uni":
+                hd = fused_epic.forward_uni(pack, mi, state.discrete.contiguous(), temb, temb_stride=stride)
+                return TensorMultiModal(None, None, hd, state.mask)
             w = {"continuous": 0, "discrete": 1}.get(which, 2)
             hc, hd = fused_epic.forward(pack, mi, state.continuous.contiguous(), state.discrete.contiguous(), temb, w,
                                         temb_stride=stride)
@@ -315,9 +327,28 @@ class MultiModalBridgeMatching(nn.Module):
         if state.has_discrete:
             state.discrete = state.discrete.clone()                   # the source tokens stay intact
         mi = self._mask_info(state)
-        pack = self._fused_pack() if (state.has_continuous and state.has_discrete) else None
+        pack = self._fused_pack()
+        if pack is not None and not self._pack_serves(pack, state):
+            pack = None
         only_dn = noise is None or set(noise.keys()) <= {"delta_n", "delta_w"}
-        if (pack is not None and cfg.solver_continuous in ("euler", "euler_maruyama")
+        if pack is not None and pack["kind"] == "uni" and cfg.solver_discrete == "tauleap" and only_dn:
+            dev = state.mask.device
+            tv = grid.to(dev)
+            dn = None
+            if noise and "delta_n" in noise:
+                dn = noise["delta_n"]
+                dn = (torch.stack(list(dn), 0) if isinstance(dn, (list, tuple)) else dn).contiguous().float()
+            br = self.bridge_discrete
+            key = (steps, eps, str(dev))
+            if pack.get("grid_key") != key:
+                temb_steps = self._time_embedding(tv)
+                pack["grid_key"], pack["grid"] = key, (temb_steps, fused_epic.time_vector_table(pack, temb_steps))
+            temb_steps, ctab = pack["grid"]
+            fused_epic.generate_uni(pack, mi, state.discrete, tv, temb_steps, delta_t, br.thermo_kind, br.gamma,
+                                    delta_n=dn, seed=self.seed, offset=(call_id << 16), ctab=ctab)
+            state.time = torch.full((mi.B, mi.N, 1), times[-1], device=dev)
+            return TensorMultiModal.stack([first, state], dim=0)
+        if (pack is not None and pack["kind"] == "multi" and cfg.solver_continuous in ("euler", "euler_maruyama")
                 and cfg.solver_discrete == "tauleap" and only_dn):
             # ONE launch for the whole loop: per-jet workgroups keep the state in registers
             dev = state.mask.device

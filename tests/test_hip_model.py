@@ -267,3 +267,45 @@ def test_euler_maruyama_generation_vs_oracle(golden, fused):
     state2 = TensorMultiModal(torch.zeros_like(src.mask), src.continuous.clone(), src.discrete.clone(), src.mask)
     p2 = model2.simulate_dynamics(state2, batch, noise={"delta_n": c(dn)})
     assert (p2.continuous[1] - paths.continuous[1]).abs().max() > 1e-3
+
+
+@pytest.mark.parametrize("name", ["uni_mid", "S2"])
+def test_fused_uni_matches_layered(golden, name):
+    """Discrete-only UniModalEPiC (BASELINE configs[1]) through the per-jet fused kernels: logits against the
+    golden and the layered path; Philox generation deterministic and statistically like the layered one."""
+    from tensorclass import TensorMultiModal
+    from datamodules.datasets import DataCoupling
+    from mmb_hip import fused
+    g = golden(name)
+    model = build(g)
+    assert fused.eligible_uni(model) is not None
+    t = g.t
+    c = lambda a: None if a is None else a.cuda()
+    state = TensorMultiModal(c(t["time"]), None, c(t["kt"]), c(t["mask"]))
+    model.use_fused = True
+    hf = model(state, None)
+    model.use_fused = False
+    hl = model(state, None)
+    assert hf.continuous is None
+    close(hf.discrete, t["head_discrete"], rtol=1e-4, atol=2e-5)
+    close(hf.discrete, hl.discrete, rtol=1e-4, atol=2e-5)
+    B, N = 256, t["mask"].shape[1]
+    mask = torch.ones(B, N, 1, dtype=torch.int64, device="cuda")
+    tgt = TensorMultiModal(None, None, torch.zeros(B, N, 1, dtype=torch.int64, device="cuda"), mask)
+    model.config.model.num_timesteps = 12
+    outs = {}
+    for fz in (True, False):
+        model.use_fused = fz
+        model.manual_seed(7)
+        p1, _ = model.predict_step(DataCoupling(TensorMultiModal(), tgt, None), 0)
+        model.manual_seed(7)
+        p2, _ = model.predict_step(DataCoupling(TensorMultiModal(), tgt, None), 0)
+        assert torch.equal(p1.discrete, p2.discrete)
+        assert int(p1.discrete.min()) >= 0 and int(p1.discrete.max()) < 8
+        outs[fz] = p1
+    a, b = outs[True], outs[False]
+    assert torch.equal(a.mask[0], b.mask[0]) and torch.equal(a.discrete[0], b.discrete[0])
+    m = a.mask[0] > 0
+    ha = torch.bincount(a.discrete[1][m].flatten(), minlength=8).float()
+    hb = torch.bincount(b.discrete[1][m].flatten(), minlength=8).float()
+    assert (ha / ha.sum() - hb / hb.sum()).abs().max() < 0.03

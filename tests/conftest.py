@@ -36,6 +36,7 @@ class Golden:
         names = json.loads(str(z["param_names"]))
         shapes = json.loads(str(z["param_shapes"]))
         seed = int(z["seed"])
+        self.seed = seed
         self.params = {}
         for n, s in zip(names, shapes):
             key = "param:" + n

@@ -1,0 +1,68 @@
+"""Distribution parity (north_star: "distributions of generated particle pT/eta/phi, multiplicity and
+flavour counts within the reference's own run-to-run Wasserstein spread").
+
+tests/golden/dist_S3.npz (tools/make_golden_dist.py) holds, for the S3 model with the name-synthesised
+weight set, the quantile functions of 8 runs of the REFERENCE generator (1024 jets x 100 steps each,
+different torch seeds) and the pairwise W1 between those runs.  The HIP generator (fused single-launch
+loop, in-kernel Philox noise, device source sampler) must sit as close to the reference runs as they
+sit to one another."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+NQ = 257
+
+
+def _observables(x, k, mask):
+    m = mask[..., 0] > 0
+    out = {"pt": x[..., 0][m], "eta_rel": x[..., 1][m], "phi_rel": x[..., 2][m], "multiplicity": m.sum(1).double()}
+    for v in range(8):
+        out[f"count_flavour_{v}"] = ((k[..., 0] == v) & m).sum(1).double()
+    return {n: np.quantile(np.asarray(t.double().cpu().numpy()), np.linspace(0, 1, NQ)) for n, t in out.items()}
+
+
+def _w1(qa, qb):
+    return float(np.trapezoid(np.abs(qa - qb), np.linspace(0.0, 1.0, NQ)))
+
+
+def test_generated_distributions_within_reference_spread(golden):
+    import copy
+    from pipeline.configs import ExperimentConfigs
+    from model.multimodal_bridge_matching import MultiModalBridgeMatching
+    from tensorclass import TensorMultiModal
+    from datamodules.datasets import DataCoupling
+    d = np.load(os.path.join(GOLDEN, "dist_S3.npz"))
+    names = json.loads(str(d["observables"]))
+    Q, w1_mean, w1_max = d["quantiles"].astype(np.float64), d["w1_mean"], d["w1_max"]
+    R, B, steps = int(d["runs"]), int(d["jets_per_run"]), int(d["steps"])
+    g = golden("S3")
+    assert int(d["weight_seed"]) == g.seed
+    cfg = copy.deepcopy(g.cfg)
+    cfg["data"]["target_path"] = GOLDEN
+    cfg["model"]["num_timesteps"] = steps
+    model = MultiModalBridgeMatching(ExperimentConfigs(cfg))
+    model.load_state_dict(g.params, strict=True)
+    model = model.cuda().eval()
+    N = cfg["data"]["max_num_particles"]
+    tgt = TensorMultiModal(None, torch.zeros(B, N, 3, device="cuda"), torch.zeros(B, N, 1, dtype=torch.int64, device="cuda"),
+                           torch.ones(B, N, 1, dtype=torch.int64, device="cuda"))
+    report = {}
+    for seed in (101, 202):
+        model.manual_seed(seed)
+        paths, _ = model.predict_step(DataCoupling(TensorMultiModal(), tgt, None), 0)
+        ours = _observables(paths.continuous[1], paths.discrete[1], paths.mask[0])
+        for i, n in enumerate(names):
+            dist = np.mean([_w1(ours[n], Q[r, i]) for r in range(R)])
+            # reference-vs-reference W1 has mean w1_mean and max w1_max over the 28 pairs; ours-vs-reference must not
+            # exceed the largest pair by more than 25 % (+ a small absolute floor for observables with zero spread)
+            bound = 1.25 * w1_max[i] + 0.02
+            report[(seed, n)] = (dist, w1_mean[i], w1_max[i])
+            assert dist <= bound, f"{n} (seed {seed}): W1 to the reference runs {dist:.4f} > {bound:.4f}"
+    print({k: tuple(round(float(x), 4) for x in v) for k, v in report.items()})

@@ -29,6 +29,10 @@ class GradStore:
     def _key(t):
         return t.untyped_storage().data_ptr()
 
+    @staticmethod
+    def _owns_storage(t):
+        return t.is_contiguous() and t.storage_offset() == 0 and t.untyped_storage().nbytes() == t.numel() * 4
+
     def seed(self, t, g):
         """Gradient of a tensor that owns its whole storage."""
         self.bufs[self._key(t)] = (g.contiguous().reshape(-1), t)
@@ -47,6 +51,45 @@ class GradStore:
         if key not in self.bufs:
             return None
         return self.bufs[key][0].as_strided(t.shape, t.stride(), t.storage_offset())
+
+    def target(self, t):
+        """(gradient view, fresh): fresh=True means the buffer was just created UNINITIALISED (t owns its
+        whole storage), so the caller must overwrite instead of accumulate -- saves a zero-fill and an add."""
+        key = self._key(t)
+        if key not in self.bufs and self._owns_storage(t):
+            self.bufs[key] = (torch.empty(t.numel(), dtype=torch.float32, device=t.device), t)
+            return self.bufs[key][0].view(t.shape), True
+        return self.view(t), False
+
+    def add(self, t, g):
+        """grad(t) += g.  When t has no gradient yet and owns its storage, g's buffer is ADOPTED (no copy):
+        callers pass temporaries / gradients that nothing reads afterwards."""
+        key = self._key(t)
+        if key not in self.bufs and self._owns_storage(t) and g.is_contiguous() and g.numel() == t.numel() \
+                and g.untyped_storage().nbytes() == g.numel() * 4:
+            self.bufs[key] = (g.reshape(-1), t)
+        else:
+            self.view(t).add_(g)
+
+
+class Arena:
+    """One zero-filled flat buffer per backward pass for every dW/db accumulator (the weight-gradient
+    kernel accumulates with atomics) instead of two fill launches per layer."""
+
+    def __init__(self, n, device):
+        self.buf = torch.zeros(n, dtype=torch.float32, device=device)
+        self.off = 0
+
+    def take(self, shape):
+        n = 1
+        for d in shape:
+            n *= d
+        pad = (-n) % 4
+        if self.off + n > self.buf.numel():
+            return torch.zeros(shape, dtype=torch.float32, device=self.buf.device)
+        out = self.buf[self.off:self.off + n].view(shape)
+        self.off += n + pad
+        return out
 
 
 def _acc_param(p, g):
@@ -76,7 +119,7 @@ def _produced(tape):
     return keys
 
 
-def _linear_bwd(e, store, produced, mi, seed):
+def _linear_bwd(e, store, produced, mi, seed, arena):
     _, layer, N, segs, act, res1, post, res2, pre, y1, y2, p, off = e
     gY1, gY2 = store.get(y1), store.get(y2)
     if gY1 is None and gY2 is None:
@@ -85,13 +128,16 @@ def _linear_bwd(e, store, produced, mi, seed):
     M, Nout = ref.shape
     dZ = ops.act_bwd(M, Nout, gY1, gY2, y1, y2, res2, pre, act, post, p, seed, off)
     if res2 is not None and gY2 is not None and GradStore._key(res2) in produced:
-        store.view(res2).add_(gY2)
+        store.add(res2, gY2)            # y2's gradient is final here: nothing reads it after its producer
     if res1 is not None and GradStore._key(res1) in produced:
-        store.view(res1).add_(dZ)
+        if any(GradStore._key(t) == GradStore._key(res1) for t, _ in segs):
+            store.view(res1).add_(dZ)   # (the input gradient below is written into the same buffer)
+        else:
+            store.add(res1, dZ)         # dZ is only READ below
     # ---- parameters
     W, inv = layer.weight(want_inv=True)
-    dW = torch.zeros_like(W)
-    db = torch.zeros(Nout, dtype=torch.float32, device=W.device)
+    dW = arena.take(W.shape)
+    db = arena.take((Nout,))
     maskf = mi.maskf
     ops.grad_weight(segs, N, maskf, dZ, dW, db)
     roff, rlen = layer._row_tables(W.device)
@@ -111,10 +157,11 @@ def _linear_bwd(e, store, produced, mi, seed):
     for (t, kind), nd in zip(segs, need):
         Ks = t.shape[1]
         if nd:
-            gx = store.view(t)
+            gx, fresh = store.target(t)
+            res = None if fresh else gx
             Wseg = WT[koff:koff + Ks]
             if kind == SEG_ROW:
-                ops.linear_cat([(dZ, SEG_ROW)], Wseg, None, N, residual=gx, out=gx)
+                ops.linear_cat([(dZ, SEG_ROW)], Wseg, None, N, residual=res, out=gx)
             else:
                 if kind == SEG_JET:
                     if S is None:
@@ -124,7 +171,7 @@ def _linear_bwd(e, store, produced, mi, seed):
                     if Sm is None:
                         Sm = ops.jet_sum(dZ, B, N, maskf=maskf)
                     red = Sm
-                ops.linear_cat([(red, SEG_ROW)], Wseg, None, 1, residual=gx, out=gx)
+                ops.linear_cat([(red, SEG_ROW)], Wseg, None, 1, residual=res, out=gx)
         koff += Ks
 
 
@@ -163,14 +210,17 @@ def run_backward(model, tape, heads, d_hc, d_hd, d_s=None, scale=None):
     produced = _produced(tape)
     mi = next(e[3] for e in tape if e[0] == "embed")
     seed = model.seed
+    n_acc = sum(e[1].weight_v.numel() + e[1].weight_v.shape[0] + 8 for e in tape if e[0] == "linear")
+    arena = Arena(n_acc, mi.maskf.device)
     for e in reversed(tape):
         kind = e[0]
         if kind == "linear":
-            _linear_bwd(e, store, produced, mi, seed)
+            _linear_bwd(e, store, produced, mi, seed, arena)
         elif kind == "pool":
             gP = store.get(e[2])
             if gP is not None and GradStore._key(e[1]) in produced:
-                ops.pool_bwd(gP, mi, store.view(e[1]), True)
+                gx, fresh = store.target(e[1])
+                ops.pool_bwd(gP, mi, gx, not fresh)
         elif kind == "cat":
             g = store.get(e[2])
             if g is not None:

@@ -181,6 +181,12 @@ int mmb_weight_norm(int n_rows, const int32_t* row_off, const int32_t* row_len,
 int mmb_weight_norm_bwd(int n_rows, const int32_t* row_off, const int32_t* row_len,
                         const float* v, const float* g, const float* inv_norm, const float* dW,
                         float* dv, float* dg, void* stream);
+/* as above with dW given as `replicas` partial copies rep_stride floats apart (summed on read) and,
+ * optionally, the bias gradient: db_out[r] = sum_q db_rep[q*db_stride + r] (both NULL to skip). */
+int mmb_weight_norm_bwd_rep(int n_rows, const int32_t* row_off, const int32_t* row_len,
+                            const float* v, const float* g, const float* inv_norm, const float* dW,
+                            int replicas, int64_t rep_stride, const float* db_rep, int64_t db_stride,
+                            float* dv, float* dg, float* db_out, void* stream);
 
 /* Y = act( cat_s[X_s] @ W^T + bias ) (+ residual): the weight-normed Linear of epic.py
  * (F.linear on a torch.cat of [time | x_local | broadcast global], epic.py:95,155,203) with
@@ -255,6 +261,18 @@ int mmb_grad_weight(int M, int rows_per_jet, int n_seg,
                     const int* seg_kind_host, const int* seg_ld_host, const float* maskf,
                     const float* dZ, int64_t dz_ld, int Nout, float* dW, int64_t dw_ld, float* db,
                     void* stream);
+
+/* Row-streaming weight gradient of ONE row-major input: dW (Nout,K) += dZ^T X, db (Nout) += colsum(dZ)
+ * (db may be NULL).  X is a per-particle input (M = B*N rows) or a per-jet matrix (M = B rows; the
+ * broadcast time / global-vector segments of a layer are handled by passing the per-jet sums of dZ,
+ * mmb_jet_sum, as dZ).  Replaces the autograd of F.linear's weight (Lightning's loss.backward() over
+ * epic.py:95-96,155,195-205) like mmb_grad_weight; buffers must be pre-zeroed (atomic accumulation).
+ * Same-address atomics serialise at the memory side, so the accumulators may be spread over
+ * `replicas` copies (dW + r*rep_stride, db + r*db_stride, block x uses copy x % replicas) that the
+ * consumer sums (mmb_weight_norm_bwd_rep does it on the way in); replicas = 1 for a single copy. */
+int mmb_grad_weight_rows(int M, const float* X, int64_t x_ld, int K, const float* dZ, int64_t dz_ld,
+                         int Nout, float* dW, int64_t dw_ld, float* db,
+                         int replicas, int64_t rep_stride, int64_t db_stride, void* stream);
 
 /* ---------------------------------------------------------------- K-E fused (generation) */
 /* Whole MultiModalEPiC forward (multimodal_epic.py:158-194 incl. embedder.py:74-80) for one jet

@@ -2,6 +2,7 @@
 // per-jet column sums, weight gradient (fp32 MFMA, dZ^T @ cat(X) with the concatenation never
 // materialised), pooling gradient.  Reference: the autograd of encoders/epic.py layers.
 #include "common.h"
+#include <stdlib.h>
 #include <utility>
 
 namespace mmb {
@@ -224,9 +225,170 @@ grad_weight_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restr
   });
 }
 
+// ---- weight gradient, row-streaming form ------------------------------------------------------
+// dW[o][k] (+)= sum_rows dZ[row][o] * X[row][k] for ONE row-major input X (a per-particle ROW
+// segment with M = B*N rows, or a per-jet matrix with M = B rows: the broadcast segments of a layer
+// enter through the jet sums of dZ).  A 64x64 layer is a 67 MB stream against 7 us of MFMA work, so
+// the kernel is built around bytes in flight: every wave streams its OWN 16-row chunks with
+// dwordx4 loads (1 KiB per instruction, each operand byte fetched exactly once per block), parks
+// them in a wave-private LDS tile and reads the MFMA fragments back transposed: lane l takes
+// dZ[row][o0 + 32 ot + (l&31)] as the A operand (m = o) and X[row][k0 + 32 kt + (l&31)] as the B
+// operand (n = k) of v_mfma_f32_32x32x2_f32, lane half l>>5 = row parity.  No block barrier inside
+// the stream (a wave only reads what it wrote).  The four waves' partial tiles are summed through
+// LDS and leave as one atomicAdd per element and block; db is the column sum of the A values.
+// Requires K and Nout to be multiples of 4 and 16-byte aligned rows (ragged last windows are zero-filled).
+template <int OT, int KT>
+__global__ void __launch_bounds__(256)
+grad_weight_rows_kernel(int M, const float* __restrict__ X, int64_t x_ld, int K, const float* __restrict__ dZ,
+                        int64_t dz_ld, int Nout, float* __restrict__ dW, int64_t dw_ld, float* __restrict__ db,
+                        int rows_per_block, int replicas, int64_t rep_stride, int64_t db_stride) {
+  constexpr int R = 16;                                  // rows per chunk
+  {                                                      // this block's replica of the accumulators
+    const int rep = blockIdx.x % replicas;
+    dW += rep * rep_stride;
+    if (db != nullptr) db += rep * db_stride;
+  }
+  constexpr int KW = 32 * KT, OW = 32 * OT;              // window widths
+  constexpr int XP = KW + 4, ZP = OW + 4;                // LDS pitches (floats)
+  constexpr int XF4 = R * KW / 4 / 64, ZF4 = R * OW / 4 / 64;   // dwordx4 per lane and chunk
+  constexpr int TILE = R * (XP + ZP);                    // floats per wave
+  constexpr int REDN = OT * KT * 16 * 64;
+  constexpr int LDSN = 4 * TILE > REDN ? 4 * TILE : REDN;
+  __shared__ __attribute__((aligned(16))) float lds[LDSN];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, i32 = lane & 31;
+  const int o0 = blockIdx.z * OW, k0 = blockIdx.y * KW;
+  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_end = min(M, r_begin + rows_per_block);
+  float* xs = lds + wave * TILE;
+  float* zs = xs + R * XP;
+
+  f32x16 acc[OT][KT];
+  sfor<OT>([&](auto oc) { sfor<KT>([&](auto kc) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[decltype(oc)::v][decltype(kc)::v][e] = 0.0f; }); });
+  float dbs[OT];
+  sfor<OT>([&](auto c) { dbs[decltype(c)::v] = 0.0f; });
+
+  // per-lane position inside a chunk for each of its dwordx4 loads
+  int xr[XF4], xc[XF4], zr[ZF4], zc[ZF4];
+  sfor<XF4>([&](auto c) { constexpr int i = decltype(c)::v; const int f = i * 64 + lane; xr[i] = f / (KW / 4); xc[i] = 4 * (f % (KW / 4)); });
+  sfor<ZF4>([&](auto c) { constexpr int i = decltype(c)::v; const int f = i * 64 + lane; zr[i] = f / (OW / 4); zc[i] = 4 * (f % (OW / 4)); });
+
+  float4 xn[XF4], zn[ZF4];
+  auto load_chunk = [&](int row0) {                      // rows past the end are clamped here, zeroed at the park
+    sfor<XF4>([&](auto c) { constexpr int i = decltype(c)::v;
+      const int64_t rr = min(row0 + xr[i], r_end - 1);
+      xn[i] = make_float4(0.f, 0.f, 0.f, 0.f);                 // columns past K (ragged last window) stay zero
+      if (k0 + xc[i] < K) xn[i] = *reinterpret_cast<const float4*>(X + rr * x_ld + k0 + xc[i]); });
+    sfor<ZF4>([&](auto c) { constexpr int i = decltype(c)::v;
+      const int64_t rr = min(row0 + zr[i], r_end - 1);
+      zn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (o0 + zc[i] < Nout) zn[i] = *reinterpret_cast<const float4*>(dZ + rr * dz_ld + o0 + zc[i]); });
+  };
+  auto park_chunk = [&](int row0) {
+    sfor<XF4>([&](auto c) { constexpr int i = decltype(c)::v;
+      *reinterpret_cast<float4*>(xs + xr[i] * XP + xc[i]) = xn[i]; });
+    sfor<ZF4>([&](auto c) { constexpr int i = decltype(c)::v;
+      float4 v = zn[i];
+      if (row0 + zr[i] >= r_end) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(zs + zr[i] * ZP + zc[i]) = v; });
+  };
+
+  // wave w owns chunks w, w+4, ... of the block
+  const int stride = 4 * R;
+  int row0 = r_begin + wave * R;
+  if (row0 < r_end) load_chunk(row0);
+  for (; row0 < r_end; row0 += stride) {
+    park_chunk(row0);                                   // (waits for the loads of this chunk)
+    if (row0 + stride < r_end) load_chunk(row0 + stride);
+#pragma unroll
+    for (int p = 0; p < R / 2; ++p) {
+      float a[OT], b[KT];
+      sfor<OT>([&](auto c) { constexpr int t = decltype(c)::v; a[t] = zs[(2 * p + half) * ZP + 32 * t + i32]; });
+      sfor<KT>([&](auto c) { constexpr int t = decltype(c)::v; b[t] = xs[(2 * p + half) * XP + 32 * t + i32]; });
+      sfor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+        dbs[ot] += a[ot];
+        sfor<KT>([&](auto kc) { constexpr int kt = decltype(kc)::v;
+          acc[ot][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ot], b[kt], acc[ot][kt], 0, 0, 0); }); });
+    }
+  }
+
+  // block reduction of the four waves' tiles: wave 0 stores, waves 1..2 add, wave 3 adds and flushes
+  __syncthreads();                                       // every wave is done with its private tile
+  auto each = [&](auto&& fn) {                           // value = fn(slot, value) over this lane's accumulators
+    sfor<OT>([&](auto oc) { sfor<KT>([&](auto kc) {
+      constexpr int ot = decltype(oc)::v, kt = decltype(kc)::v;
+      sfor<16>([&](auto ec) { constexpr int e = decltype(ec)::v;
+        acc[ot][kt][e] = fn(&lds[((ot * KT + kt) * 16 + e) * 64 + lane], acc[ot][kt][e]); }); }); });
+  };
+  if (wave == 0) each([](float* slot, float v) { *slot = v; return v; });
+  __syncthreads();
+  if (wave == 1) each([](float* slot, float v) { *slot += v; return v; });
+  __syncthreads();
+  if (wave == 2) each([](float* slot, float v) { *slot += v; return v; });
+  __syncthreads();
+  if (wave == 3) each([](float* slot, float v) { return v + *slot; });
+  if (wave == 3) {
+    sfor<OT>([&](auto oc) { sfor<KT>([&](auto kc) {
+      constexpr int ot = decltype(oc)::v, kt = decltype(kc)::v;
+      const int col = k0 + 32 * kt + i32;
+      sfor<16>([&](auto ec) { constexpr int e = decltype(ec)::v;
+        const int o = o0 + 32 * ot + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (o < Nout && col < K) atomicAdd(&dW[(int64_t)o * dw_ld + col], acc[ot][kt][e]); }); }); });
+  }
+  // db: one atomic per column and BLOCK (same-address atomics serialise at the memory side: ~60 ns each)
+  if (db != nullptr && blockIdx.y == 0) {
+    sfor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+      float v = dbs[ot];
+      v += __shfl_xor(v, 32, 64);
+      if (half == 0) lds[wave * OW + 32 * ot + i32] = v; });
+    __syncthreads();
+    if (threadIdx.x < OW && o0 + (int)threadIdx.x < Nout) {
+      const int c = threadIdx.x;
+      atomicAdd(&db[o0 + c], (lds[c] + lds[OW + c]) + (lds[2 * OW + c] + lds[3 * OW + c]));
+    }
+  }
+}
+
 }  // namespace mmb
 
 using namespace mmb;
+
+extern "C" int mmb_grad_weight_rows(int M, const float* X, int64_t x_ld, int K, const float* dZ, int64_t dz_ld,
+                                    int Nout, float* dW, int64_t dw_ld, float* db, int replicas, int64_t rep_stride,
+                                    int64_t db_stride, void* stream) {
+  MMB_REQUIRE(replicas >= 1 && replicas <= 64, "mmb_grad_weight_rows: replicas=%d outside [1,64]", replicas);
+  MMB_REQUIRE(M > 0 && K > 0 && Nout > 0, "mmb_grad_weight_rows: empty shape M=%d K=%d Nout=%d", M, K, Nout);
+  MMB_REQUIRE(X && dZ && dW, "mmb_grad_weight_rows: NULL argument");
+  MMB_REQUIRE(x_ld >= K && dz_ld >= Nout && dw_ld >= K, "mmb_grad_weight_rows: leading dimension too small");
+  const bool fast = (K % 4 == 0) && (Nout % 4 == 0) && (x_ld % 4 == 0) && (dz_ld % 4 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dZ) & 15) == 0);
+  if (!fast) {                                           // ragged widths: the generic segment kernel
+    const void* ptr[1] = {X};
+    int width[1] = {K}, kind[1] = {MMB_SEG_ROW}, ld[1] = {(int)x_ld};
+    return mmb_grad_weight(M, 1, 1, ptr, width, kind, ld, nullptr, dZ, dz_ld, Nout, dW, dw_ld, db, stream);
+  }
+  const int ot_all = (Nout + 31) / 32, kt_all = (K + 31) / 32;
+  int OTb = ot_all >= 4 ? 4 : (ot_all >= 2 ? 2 : 1);
+  int KTb = kt_all >= 4 ? 4 : (kt_all >= 2 ? 2 : 1);
+  while (OTb * KTb > 8) { if (KTb >= OTb) KTb /= 2; else OTb /= 2; }
+  int rpb = 512;                                         // 8 chunks per wave
+  if (M <= 16384) rpb = 64;
+  if (const char* e = getenv("MMB_GW_RPB")) rpb = atoi(e) > 0 ? atoi(e) : rpb;      // tuning knob
+  dim3 grid((M + rpb - 1) / rpb, (kt_all + KTb - 1) / KTb, (ot_all + OTb - 1) / OTb);
+  hipStream_t st = as_stream(stream);
+#define GWR(O_, K_) hipLaunchKernelGGL((grad_weight_rows_kernel<O_, K_>), grid, dim3(256), 0, st, M, X, x_ld, K, dZ, dz_ld, Nout, dW, dw_ld, db, rpb, replicas, rep_stride, db_stride)
+  if (OTb == 1 && KTb == 1) GWR(1, 1);
+  else if (OTb == 1 && KTb == 2) GWR(1, 2);
+  else if (OTb == 1 && KTb == 4) GWR(1, 4);
+  else if (OTb == 2 && KTb == 1) GWR(2, 1);
+  else if (OTb == 2 && KTb == 2) GWR(2, 2);
+  else if (OTb == 2 && KTb == 4) GWR(2, 4);
+  else if (OTb == 4 && KTb == 1) GWR(4, 1);
+  else GWR(4, 2);
+#undef GWR
+  return check_launch("mmb_grad_weight_rows");
+}
 
 extern "C" int mmb_act_bwd(int64_t M, int Nout, const float* gY1, int64_t gY1_ld, const float* gY2, int64_t gY2_ld,
                            const float* y1, int64_t y1_ld, const float* y2, int64_t y2_ld, const float* res2,

@@ -264,22 +264,38 @@ weight_norm_kernel(int n_rows, const int32_t* __restrict__ row_off, const int32_
   if (inv_norm && threadIdx.x == 0) inv_norm[r] = 1.0f / nrm;
 }
 
+// dW (and db) may arrive as `reps` partial replicas (rep_stride / db_stride floats apart): the
+// weight-gradient kernel spreads its atomics over replicas because same-address atomics serialise
+// at the memory side; they are summed here, on the way in.
 __global__ void __launch_bounds__(64)
 weight_norm_bwd_kernel(int n_rows, const int32_t* __restrict__ row_off, const int32_t* __restrict__ row_len,
                        const float* __restrict__ v, const float* __restrict__ g,
-                       const float* __restrict__ inv_norm, const float* __restrict__ dW,
-                       float* __restrict__ dv, float* __restrict__ dg) {
+                       const float* __restrict__ inv_norm, const float* __restrict__ dW, int reps,
+                       int64_t rep_stride, const float* __restrict__ db_rep, int64_t db_stride,
+                       float* __restrict__ dv, float* __restrict__ dg, float* __restrict__ db_out) {
   const int r = blockIdx.x;
   const int off = row_off[r], len = row_len[r];
+  auto dw_at = [&](int k) {
+    float s = dW[off + k];
+    for (int q = 1; q < reps; ++q) s += dW[q * rep_stride + off + k];
+    return s;
+  };
   float dot = 0.0f;
-  for (int k = threadIdx.x; k < len; k += 64) dot += dW[off + k] * v[off + k];
+  for (int k = threadIdx.x; k < len; k += 64) dot += dw_at(k) * v[off + k];
   dot = wave_sum(dot);
   const float inv = inv_norm[r];
   const float gg = g[r];
   const float c1 = gg * inv;
   const float c2 = gg * dot * inv * inv * inv;
-  for (int k = threadIdx.x; k < len; k += 64) dv[off + k] = c1 * dW[off + k] - c2 * v[off + k];
-  if (threadIdx.x == 0) dg[r] = dot * inv;
+  for (int k = threadIdx.x; k < len; k += 64) dv[off + k] = c1 * dw_at(k) - c2 * v[off + k];
+  if (threadIdx.x == 0) {
+    dg[r] = dot * inv;
+    if (db_out != nullptr) {
+      float s = 0.0f;
+      for (int q = 0; q < reps; ++q) s += db_rep[q * db_stride + r];
+      db_out[r] = s;
+    }
+  }
 }
 
 // ---------------------------------------------------------------- pooling --------------
@@ -447,14 +463,24 @@ extern "C" int mmb_weight_norm(int n_rows, const int32_t* row_off, const int32_t
   return check_launch("mmb_weight_norm");
 }
 
+extern "C" int mmb_weight_norm_bwd_rep(int n_rows, const int32_t* row_off, const int32_t* row_len, const float* v,
+                                       const float* g, const float* inv_norm, const float* dW, int replicas,
+                                       int64_t rep_stride, const float* db_rep, int64_t db_stride, float* dv,
+                                       float* dg, float* db_out, void* stream) {
+  MMB_REQUIRE(n_rows > 0, "mmb_weight_norm_bwd: n_rows=%d", n_rows);
+  MMB_REQUIRE(row_off && row_len && v && g && inv_norm && dW && dv && dg, "mmb_weight_norm_bwd: NULL argument");
+  MMB_REQUIRE(replicas >= 1 && replicas <= 64, "mmb_weight_norm_bwd: replicas=%d outside [1,64]", replicas);
+  MMB_REQUIRE((db_out == nullptr) == (db_rep == nullptr), "mmb_weight_norm_bwd: db_rep and db_out go together");
+  hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(n_rows), dim3(64), 0, as_stream(stream), n_rows, row_off,
+                     row_len, v, g, inv_norm, dW, replicas, rep_stride, db_rep, db_stride, dv, dg, db_out);
+  return check_launch("mmb_weight_norm_bwd");
+}
+
 extern "C" int mmb_weight_norm_bwd(int n_rows, const int32_t* row_off, const int32_t* row_len, const float* v,
                                    const float* g, const float* inv_norm, const float* dW, float* dv, float* dg,
                                    void* stream) {
-  MMB_REQUIRE(n_rows > 0, "mmb_weight_norm_bwd: n_rows=%d", n_rows);
-  MMB_REQUIRE(row_off && row_len && v && g && inv_norm && dW && dv && dg, "mmb_weight_norm_bwd: NULL argument");
-  hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(n_rows), dim3(64), 0, as_stream(stream), n_rows, row_off,
-                     row_len, v, g, inv_norm, dW, dv, dg);
-  return check_launch("mmb_weight_norm_bwd");
+  return mmb_weight_norm_bwd_rep(n_rows, row_off, row_len, v, g, inv_norm, dW, 1, 0, nullptr, 0, dv, dg, nullptr,
+                                 stream);
 }
 
 extern "C" int mmb_meansum_pool(int B, int N, int H, const float* x, int64_t x_ld, const float* maskf,

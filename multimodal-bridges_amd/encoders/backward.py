@@ -21,6 +21,9 @@ from mmb_hip import ops
 from mmb_hip.ops import SEG_ROW, SEG_JET, SEG_JET_MASK
 
 
+GW_REPLICAS = 8
+
+
 class GradStore:
     def __init__(self):
         self.bufs = {}
@@ -136,13 +139,36 @@ def _linear_bwd(e, store, produced, mi, seed, arena):
             store.add(res1, dZ)         # dZ is only READ below
     # ---- parameters
     W, inv = layer.weight(want_inv=True)
-    dW = arena.take(W.shape)
-    db = arena.take((Nout,))
+    R = GW_REPLICAS if M >= 16384 else 1                # same-address atomics serialise: spread them
+    Kall = W.shape[1]
+    dWr = arena.take((R, Nout * Kall))
+    dbr = arena.take((R, Nout))
+    dW = dWr[0].view(Nout, Kall)
+    db = dbr[0]
+    rep = dict(replicas=R, rep_stride=dWr.stride(0), db_stride=dbr.stride(0))
     maskf = mi.maskf
-    ops.grad_weight(segs, N, maskf, dZ, dW, db)
+    B = mi.B
+    S = Sm = None
+    koff = 0
+    first = True
+    for t, kind in segs:                                # per-particle inputs stream; broadcast inputs go
+        Ks = t.shape[1]                                 # through the per-jet sums of dZ (M = B rows)
+        dWs = dW[:, koff:koff + Ks]
+        if kind == SEG_ROW:
+            ops.grad_weight_rows(t, dZ, dWs, db if first else None, **rep)
+            first = False
+        elif kind == SEG_JET:
+            if S is None:
+                S = ops.jet_sum(dZ, B, N)
+            ops.grad_weight_rows(t, S, dWs, None)
+        else:
+            if Sm is None:
+                Sm = ops.jet_sum(dZ, B, N, maskf=maskf)
+            ops.grad_weight_rows(t, Sm, dWs, None)
+        koff += Ks
     roff, rlen = layer._row_tables(W.device)
-    dv, dg = ops.weight_norm_bwd(roff, rlen, layer.weight_v.detach().reshape(-1), layer.weight_g.detach().reshape(-1),
-                                 inv, dW.reshape(-1))
+    dv, dg, db = ops.weight_norm_bwd_rep(roff, rlen, layer.weight_v.detach().reshape(-1),
+                                         layer.weight_g.detach().reshape(-1), inv, dWr, dbr)
     _acc_param(layer.weight_v, dv)
     _acc_param(layer.weight_g, dg)
     _acc_param(layer.bias, db)
@@ -151,8 +177,6 @@ def _linear_bwd(e, store, produced, mi, seed, arena):
     if not any(need):
         return
     WT = W.t().contiguous()
-    B = mi.B
-    S = Sm = None
     koff = 0
     for (t, kind), nd in zip(segs, need):
         Ks = t.shape[1]
@@ -210,7 +234,7 @@ def run_backward(model, tape, heads, d_hc, d_hd, d_s=None, scale=None):
     produced = _produced(tape)
     mi = next(e[3] for e in tape if e[0] == "embed")
     seed = model.seed
-    n_acc = sum(e[1].weight_v.numel() + e[1].weight_v.shape[0] + 8 for e in tape if e[0] == "linear")
+    n_acc = sum(GW_REPLICAS * (e[1].weight_v.numel() + e[1].weight_v.shape[0] + 8) for e in tape if e[0] == "linear")
     arena = Arena(n_acc, mi.maskf.device)
     for e in reversed(tape):
         kind = e[0]

@@ -377,3 +377,28 @@ def grad_weight(segs, rows_per_jet, maskf, dZ, dW, db):
     Nout = dZ.shape[1]
     call("mmb_grad_weight", M, rows_per_jet, n, ptrs, widths, kinds, lds, f32(maskf), dZ.data_ptr(), dZ.stride(0),
          Nout, dW.data_ptr(), dW.stride(0), db.data_ptr() if db is not None else None, stream())
+
+
+def grad_weight_rows(X, dZ, dW, db=None, replicas=1, rep_stride=0, db_stride=0):
+    """dW (Nout,K) += dZ^T @ X for one row-major input X (M,K) [row stride may exceed K]; db += colsum(dZ).
+    dW may be a column slice of a wider weight gradient.  Buffers must be pre-zeroed.  With replicas > 1
+    the accumulation is spread over copies dW + r*rep_stride / db + r*db_stride (floats) that the caller sums."""
+    for t, name in ((X, "X"), (dZ, "dZ"), (dW, "dW")):
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+            raise MMBError(f"grad_weight_rows: {name} must be a 2-D float32 HIP tensor with unit inner stride")
+    if X.shape[0] != dZ.shape[0] or dW.shape != (dZ.shape[1], X.shape[1]):
+        raise MMBError("grad_weight_rows: shape mismatch")
+    call("mmb_grad_weight_rows", X.shape[0], X.data_ptr(), X.stride(0), X.shape[1], dZ.data_ptr(), dZ.stride(0),
+         dZ.shape[1], dW.data_ptr(), dW.stride(0), db.data_ptr() if db is not None else None, replicas, rep_stride,
+         db_stride, stream())
+
+
+def weight_norm_bwd_rep(row_off, row_len, v_flat, g_flat, inv, dW_rep, db_rep):
+    """dW_rep (R, Nout*K) and db_rep (R, Nout) replicas -> (dv, dg, db)"""
+    dv = torch.empty_like(v_flat)
+    dg = torch.empty_like(g_flat)
+    db = torch.empty(g_flat.numel(), dtype=torch.float32, device=v_flat.device)
+    call("mmb_weight_norm_bwd_rep", g_flat.numel(), i32(row_off), i32(row_len), f32(v_flat), f32(g_flat), f32(inv),
+         f32(dW_rep), dW_rep.shape[0], dW_rep.stride(0), f32(db_rep), db_rep.stride(0), f32(dv), f32(dg), f32(db),
+         stream())
+    return dv, dg, db

@@ -311,3 +311,25 @@ def test_invalid_arguments_raise(ops):
     with pytest.raises(MMBError):
         ops.telegraph_rate(torch.zeros(1, 1, 8, device="cuda"), torch.zeros(1, 1, 1, dtype=torch.int64, device="cuda"),
                            None, 0.5, 9, 0.1)                           # bad thermostat
+
+
+@pytest.mark.parametrize("M,K,Nout,x_pad", [
+    (131, 64, 64, 0), (4096, 64, 64, 8), (1024, 288, 128, 0), (777, 16, 3, 0), (2049, 128, 128, 32),
+    (64, 37, 70, 3), (5000, 144, 64, 0), (300, 128, 8, 0)])
+def test_grad_weight_rows(ops, M, K, Nout, x_pad):
+    """Row-streaming weight gradient against a plain torch fp32 matmul (ragged rows/columns, strided X,
+    dW written into a column slice of a wider gradient, atomic accumulation on top of existing values)."""
+    g = torch.Generator().manual_seed(M + K + Nout)
+    Xfull = torch.randn(M, K + x_pad, generator=g).cuda()
+    X = Xfull[:, x_pad:] if x_pad else Xfull
+    dZ = torch.randn(M, Nout, generator=g).cuda()
+    wide = torch.zeros(Nout, K + 5, device="cuda")
+    wide[:, :] = 0.25
+    dW = wide[:, 2:2 + K]
+    db = torch.full((Nout,), -1.0, device="cuda")
+    ops.grad_weight_rows(X, dZ, dW, db)
+    want = dZ.double().t() @ X.double()
+    scale = float(want.abs().max())
+    close(dW.double() - 0.25, want, rtol=1e-4, atol=2e-5 * scale)
+    close(db.double() + 1.0, dZ.double().sum(0), rtol=1e-4, atol=2e-5 * float(dZ.abs().sum(0).max()))
+    assert float((wide[:, :2] - 0.25).abs().max()) == 0.0 and float((wide[:, 2 + K:] - 0.25).abs().max()) == 0.0

@@ -99,6 +99,7 @@ struct alignas(16) Lds {
   float table[8 * 32];            // discrete embedding table [V<=8][Ed<=32]
   float cnt;
   int red[4];
+  float park[4][FE_THREADS];      // generation loop: x (3) and k of this lane's particle while a forward runs
 #ifdef MMB_FE_PROF
   unsigned long long tlast;
 #endif
@@ -202,6 +203,21 @@ __device__ __forceinline__ f32x16 fetch_tile(const float4* S, int t, int tid) {
   return v;
 }
 
+// Weight fragments are fetched with BUFFER loads: one descriptor for the packed parameter block
+// (SGPRs), the per-lane part of the address is the constant lane*16 in ONE VGPR, the fragment's
+// position is a wave-uniform SGPR offset -- no 64-bit per-load address arithmetic and no address
+// registers for the allocator to keep alive across the MFMA stream.
+typedef __amdgpu_buffer_rsrc_t WRsrc;
+__device__ __forceinline__ WRsrc weight_rsrc(const float* P) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, 0x7FFFFFFC, 0x00020000);
+}
+// float4 at packed float offset `woff` (uniform) + 64*f4 (uniform, float4 units) + this lane's float4
+__device__ __forceinline__ float4 wload(WRsrc R, int woff, int f4, int lane16) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(R, lane16, (woff + 4 * f4) * 4, 0);
+  static_assert(sizeof(v) == 16, "b128 buffer load");
+  return __builtin_bit_cast(float4, v);
+}
+
 // First A-operand group (k-steps 0..3 of every output tile) of a packed weight matrix, fetched
 // ahead of the GEMM that uses it -- while the previous GEMM or the per-jet chain runs -- so that no
 // GEMM starts with an exposed L2 round trip.
@@ -210,9 +226,8 @@ struct AFrag {
   float4 a[OT];
 };
 template <int OT>
-__device__ __forceinline__ void mma_prefetch(AFrag<OT>& f, const float* __restrict__ Wp, int lane) {
-  const float4* w4 = reinterpret_cast<const float4*>(Wp) + lane;
-  ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; f.a[ot] = w4[ot * 64]; });
+__device__ __forceinline__ void mma_prefetch(AFrag<OT>& f, WRsrc R, int woff, int lane) {
+  ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; f.a[ot] = wload(R, woff, ot * 64, lane * 16); });
 }
 
 // acc[ot] += W_x (tile rows ot) * X^T, X^T tiles delivered by `tile(IF<ft>)` (a reference to
@@ -220,18 +235,18 @@ __device__ __forceinline__ void mma_prefetch(AFrag<OT>& f, const float* __restri
 // lane and tile) run D groups ahead of the MFMAs through a ring of D+1 register buffers; D is
 // chosen so that the look-ahead is ~1000 MFMA cycles whatever OT is.
 template <int KT, int OT, typename TileFn>
-__device__ __forceinline__ void mma_x(f32x16 (&acc)[OT], TileFn&& tile, const float* __restrict__ Wp, int lane,
+__device__ __forceinline__ void mma_x(f32x16 (&acc)[OT], TileFn&& tile, WRsrc R, int woff, int lane,
                                       const AFrag<OT>& pre) {
   constexpr int NG = KT * 4;
   constexpr int D0 = OT >= 4 ? 1 : (OT == 2 ? 2 : 4);
   constexpr int D = D0 < NG - 1 ? D0 : (NG - 1 > 0 ? NG - 1 : 1);
-  const float4* w4 = reinterpret_cast<const float4*>(Wp) + lane;
+  const int lane16 = lane * 16;
   float4 ring[D + 1][OT];
   ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; ring[0][ot] = pre.a[ot]; });
   ffor<D - 1>([&](auto dc) {
     constexpr int g = 1 + decltype(dc)::v;
     if constexpr (g < NG)
-      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; ring[g][ot] = w4[(g * OT + ot) * 64]; });
+      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; ring[g][ot] = wload(R, woff, (g * OT + ot) * 64, lane16); });
   });
   ffor<KT>([&](auto fc) {
     constexpr int ft = decltype(fc)::v;
@@ -242,7 +257,7 @@ __device__ __forceinline__ void mma_x(f32x16 (&acc)[OT], TileFn&& tile, const fl
       constexpr int cur = g % (D + 1);
       if constexpr (g + D < NG)
         ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-          ring[(g + D) % (D + 1)][ot] = w4[((g + D) * OT + ot) * 64]; });
+          ring[(g + D) % (D + 1)][ot] = wload(R, woff, ((g + D) * OT + ot) * 64, lane16); });
       ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
         acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[cur][ot].x, xt[4 * q + 0], acc[ot], 0, 0, 0); });
       ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
@@ -363,12 +378,13 @@ struct Epic {
                                                const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
                                                float m, int tid, const float* ctab, int& ci) {
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const WRsrc R = weight_rsrc(P);
     const LDesc g1 = D[li], g2 = D[li + 1], l1 = D[li + 2], l2 = D[li + 3];
     li += 4;
     FE_PROF(L, PF_EPI);
     pool_partials<HT>(x, m, L.partial, wave, lane);
     AFrag<HT> pre1, pre2;
-    mma_prefetch(pre1, P + l1.wx, lane);               // arrives under the per-jet chain
+    if constexpr (HT <= 2) mma_prefetch(pre1, R, l1.wx, lane);   // arrives under the per-jet chain
     __syncthreads();
     FE_PROF(L, PF_POOL);
     WaveMV<2 * H + G, H>::template run<MMB_ACT_LRELU>(P + g1.wt, P + g1.b, PooledIn<H>{L.partial, L.gcur, L.cnt}, L.gh,
@@ -381,17 +397,19 @@ struct Epic {
     FE_PROF(L, PF_DVEC);
     if (tid < G) L.gcur[tid] = lrelu_f(L.gnew[tid]) + (use_skip ? L.gskip[tid] : 0.0f);
     f32x16 lh[HT];
+    if constexpr (HT > 2) mma_prefetch(pre1, R, l1.wx, lane);    // (wide encoder: no registers to spare earlier)
     acc_init<HT>(lh, m, cv, L.dvec, half);
-    mma_prefetch(pre2, P + l2.wx, lane);               // arrives under the first GEMM
-    mma_x<HT, HT>(lh, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, P + l1.wx, lane, pre1);
+    if constexpr (HT <= 2) mma_prefetch(pre2, R, l2.wx, lane);   // arrives under the first GEMM
+    mma_x<HT, HT>(lh, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, R, l1.wx, lane, pre1);
     act_tiles<HT, MMB_ACT_LRELU>(lh);
+    if constexpr (HT > 2) mma_prefetch(pre2, R, l2.wx, lane);
     FE_PROF(L, PF_LOC1);
     // x <- (x + b2) + W2 lh : the residual rides in the accumulator, x's registers ARE the accumulator
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
       ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
         const float4 bv = *reinterpret_cast<const float4*>(P + l2.b + 32 * t + 8 * q + 4 * half);
         x[t][4 * q + 0] += bv.x; x[t][4 * q + 1] += bv.y; x[t][4 * q + 2] += bv.z; x[t][4 * q + 3] += bv.w; }); });
-    mma_x<HT, HT>(x, [&](auto fc) -> const f32x16& { return lh[decltype(fc)::v]; }, P + l2.wx, lane, pre2);
+    mma_x<HT, HT>(x, [&](auto fc) -> const f32x16& { return lh[decltype(fc)::v]; }, R, l2.wx, lane, pre2);
     FE_PROF(L, PF_LOC2);
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
       if (use_skip) {
@@ -410,14 +428,15 @@ struct Epic {
                                                 const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
                                                 float m, int tid, const float* ctab, int& ci) {
     const int lane = tid & 63, half = lane >> 5;
+    const WRsrc R = weight_rsrc(P);
     const LDesc o = D[li];
     li += 1;
     AFrag<OTO> pre;
-    mma_prefetch(pre, P + o.wx, lane);
+    mma_prefetch(pre, R, o.wx, lane);
     const float* cv = time_vec<ET, OW>(ctab, ci, P + o.wt, L, tid);
     matvec<MMB_ACT_NONE, G, OW>(P + o.wg, P + o.b, L.gcur, L.dvec, nullptr, tid);
     acc_init<OTO>(out, m, cv, L.dvec, half);
-    mma_x<HT, OTO>(out, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, P + o.wx, lane, pre);
+    mma_x<HT, OTO>(out, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, R, o.wx, lane, pre);
     FE_PROF(L, PF_OUT);
   }
 
@@ -427,18 +446,19 @@ struct Epic {
                                                  const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
                                                  float m, int tid, const float* ctab, int& ci) {
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const WRsrc R = weight_rsrc(P);
     const LDesc p0 = D[li], p2 = D[li + 1], q0 = D[li + 2], q2 = D[li + 3];
     li += 4;
     AFrag<HT> pre0, pre2;
-    mma_prefetch(pre0, P + p0.wx, lane);
-    mma_prefetch(pre2, P + p2.wx, lane);
+    mma_prefetch(pre0, R, p0.wx, lane);
+    mma_prefetch(pre2, R, p2.wx, lane);
     const float* cv = time_vec<ET, H>(ctab, ci, P + p0.wt, L, tid);
     f32x16 h[HT];
     acc_init<HT>(h, m, cv, P + p0.b, half);
-    mma_x<KIN, HT>(h, xin, P + p0.wx, lane, pre0);
+    mma_x<KIN, HT>(h, xin, R, p0.wx, lane, pre0);
     act_tiles<HT, MMB_ACT_GELU>(h);
     acc_init<HT>(x, 0.0f, nullptr, P + p2.b, half);
-    mma_x<HT, HT>(x, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, P + p2.wx, lane, pre2);
+    mma_x<HT, HT>(x, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, R, p2.wx, lane, pre2);
     act_tiles<HT, MMB_ACT_GELU>(x);
     FE_PROF(L, PF_PROJ_MMA);
     pool_partials<HT>(x, m, L.partial, wave, lane);
@@ -548,6 +568,7 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
   Epic<HFT, DM::ET, DM::GF>::template output<HFT, 2 * DM::HB>(f, x, A.P, A.D, li, L, m, tid, A.ctab, ci);
   // ---- heads (multimodal_epic.py:187-189): cat[t, f_i, h_i] -> GELU -> out
   const LDesc c0 = A.D[li], c2 = A.D[li + 1], d0 = A.D[li + 2], d2 = A.D[li + 3];
+  const WRsrc R = weight_rsrc(A.P);
   FE_PROF(L, PF_EPI);
   const int ci_heads = ci;                               // table slots: [.. , continuous head, discrete head]
   if (which != 1) {
@@ -555,17 +576,17 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
     const float* cv = time_vec<DM::ET, DM::HB>(A.ctab, ci, A.P + c0.wt, L, tid);
     AFrag<HBT> pre0;
     AFrag<1> pre2;
-    mma_prefetch(pre0, A.P + c0.wx, lane);
-    mma_prefetch(pre2, A.P + c2.wx, lane);
+    mma_prefetch(pre0, R, c0.wx, lane);
+    mma_prefetch(pre2, R, c2.wx, lane);
     f32x16 h[HBT];
     acc_init<HBT>(h, m, cv, A.P + c0.b, half);
     mma_x<HFT, HBT>(h, [&](auto fc) -> f32x16 {
       constexpr int t = decltype(fc)::v;
-      if constexpr (t < HBT) return f[t]; else return fetch_tile(S, t - HBT, tid); }, A.P + c0.wx, lane, pre0);
+      if constexpr (t < HBT) return f[t]; else return fetch_tile(S, t - HBT, tid); }, R, c0.wx, lane, pre0);
     act_tiles<HBT, MMB_ACT_GELU>(h);
     f32x16 o[1];
     acc_init<1>(o, 0.0f, nullptr, A.P + c2.b, half);
-    mma_x<HBT, 1>(o, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, A.P + c2.wx, lane, pre2);
+    mma_x<HBT, 1>(o, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, R, c2.wx, lane, pre2);
     hc = o[0];
   }
   if (which != 0) {
@@ -573,17 +594,17 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
     const float* cv = time_vec<DM::ET, DM::HB>(A.ctab, ci, A.P + d0.wt, L, tid);
     AFrag<HBT> pre0;
     AFrag<1> pre2;
-    mma_prefetch(pre0, A.P + d0.wx, lane);
-    mma_prefetch(pre2, A.P + d2.wx, lane);
+    mma_prefetch(pre0, R, d0.wx, lane);
+    mma_prefetch(pre2, R, d2.wx, lane);
     f32x16 h[HBT];
     acc_init<HBT>(h, m, cv, A.P + d0.b, half);
     mma_x<HFT, HBT>(h, [&](auto fc) -> f32x16 {
       constexpr int t = decltype(fc)::v;
-      if constexpr (t < HBT) return f[HBT + t]; else return fetch_tile(S, t, tid); }, A.P + d0.wx, lane, pre0);
+      if constexpr (t < HBT) return f[HBT + t]; else return fetch_tile(S, t, tid); }, R, d0.wx, lane, pre0);
     act_tiles<HBT, MMB_ACT_GELU>(h);
     f32x16 o[1];
     acc_init<1>(o, 0.0f, nullptr, A.P + d2.b, half);
-    mma_x<HBT, 1>(o, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, A.P + d2.wx, lane, pre2);
+    mma_x<HBT, 1>(o, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, R, d2.wx, lane, pre2);
     hd = o[0];
   }
   FE_PROF(L, PF_HEAD);
@@ -744,8 +765,22 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
       A.ctab = Gn.ctab_steps ? Gn.ctab_steps + (int64_t)s * Gn.n_ctab * 128 : nullptr;
       const float tt = Gn.times[s];
       f32x16 hc, hd;
+      // The particle state is only needed at the two ends of a forward: it waits in LDS meanwhile
+      // (each lane reads back its own slot), which keeps it out of the register allocator's way.
+      auto park = [&]() {
+#pragma unroll
+        for (int d = 0; d < DM::DC; ++d) L.park[d][tid] = xp[d];
+        L.park[3][tid] = __int_as_float(kp);
+      };
+      auto unpark = [&]() {
+#pragma unroll
+        for (int d = 0; d < DM::DC; ++d) xp[d] = L.park[d][tid];
+        kp = __float_as_int(L.park[3][tid]);
+      };
       // Euler step on the drift head (solvers.py:21-25); padded slots move too (K3)
+      park();
       forward_jet<DM>(A, L, S, xp, kp, m, 0, hc, hd, tid);
+      unpark();
       {
         float v[3] = {hc[0], hc[1], hc[2]};
         float w[4] = {0.f, 0.f, 0.f, 0.f};
@@ -761,8 +796,12 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
           } else {
             uint32_t q[4];
             philox4(Gn.seed, Gn.offset + (uint64_t)s, (uint64_t)gp, 0xE001u, q);
-            box_muller(q[0], q[1], w[0], w[1]);
-            box_muller(q[2], q[3], w[2], w[3]);
+            // hardware v_sin/v_cos (argument in revolutions): distribution-level draws, and no
+            // private-memory argument reduction inside the generation loop
+            const float r0 = sqrtf(-2.0f * __logf(u01_open0(q[0]))), r1 = sqrtf(-2.0f * __logf(u01_open0(q[2])));
+            w[0] = r0 * __builtin_amdgcn_cosf(u01(q[1]));
+            w[1] = r0 * __builtin_amdgcn_sinf(u01(q[1]));
+            w[2] = r1 * __builtin_amdgcn_cosf(u01(q[3]));
           }
         }
 #pragma unroll
@@ -774,7 +813,9 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
       }
       __syncthreads();
       // tau-leap on the logits head, which sees the UPDATED x at the same t (solvers.py:59-81)
+      park();
       forward_jet<DM>(A, L, S, xp, kp, m, 1, hc, hd, tid);
+      unpark();
       float r[V];
       gather_logits<DM>(hd, r, lane);
       kp = jump_step(r, kp, tt, Gn, s == Gn.steps - 1, valid, A.B, A.N, b, p, s, gp);

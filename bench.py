@@ -31,7 +31,8 @@ import torch  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
 
-WORKLOADS = {"S3": "configs/S3_multimodal.yaml", "S2": "configs/S2_discrete.yaml"}
+WORKLOADS = {"S3": "configs/S3_multimodal.yaml", "S2": "configs/S2_discrete.yaml",
+             "S5": "configs/S5_large_generation.yaml"}
 
 
 def build_model(workload, steps_per_gen, device):
@@ -41,7 +42,8 @@ def build_model(workload, steps_per_gen, device):
     with open(os.path.join(ROOT, WORKLOADS[workload])) as fh:
         cfg = yaml.safe_load(fh)
     cfg["data"]["target_path"] = os.path.join(ROOT, "tests", "golden")
-    cfg["model"]["num_timesteps"] = steps_per_gen
+    if steps_per_gen:
+        cfg["model"]["num_timesteps"] = steps_per_gen
     config = ExperimentConfigs(cfg)
     torch.manual_seed(0)
     model = MultiModalBridgeMatching(config)
@@ -98,13 +100,14 @@ def measured_traffic(workload):
 
 
 def cpu_baseline(model, config, workload, n_jets, n_steps):
-    """CPU oracle on a bounded sample: n_jets jets, the first n_steps of the 100-point grid."""
+    """CPU oracle on a bounded sample: n_jets jets, the first n_steps of the time grid."""
     from oracle import model as OM, source as OS
     from datamodules.synthetic import load_pmf
     p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     m = config.model
     flat = {"time_eps": m.time_eps, "num_timesteps": m.num_timesteps, "gamma": m.gamma, "sigma": m.sigma,
             "thermostat_fn": m.thermostat_fn, "solver_continuous": m.solver_continuous,
+            "bridge_continuous": getattr(m, "bridge_continuous", None),
             "solver_discrete": m.solver_discrete, "vocab_size": config.data.vocab_size,
             "encoder_name": config.encoder.name, "skip_connection": config.encoder.skip_connection}
     N = config.data.max_num_particles
@@ -129,7 +132,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="S3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=1024, help="jets per rank per step")
-    ap.add_argument("--solver-steps", type=int, default=100)
+    ap.add_argument("--solver-steps", type=int, default=0, help="grid points (0: the workload's own: 100, S5: 200)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-jets", type=int, default=128)
     ap.add_argument("--cpu-steps", type=int, default=10)
@@ -149,6 +152,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     model, config = build_model(args.workload, args.solver_steps, device)
+    args.solver_steps = config.model.num_timesteps
     model.eval()
     model.manual_seed(0xA0A0, rank)
     B = args.batch
@@ -217,7 +221,7 @@ def main():
                     "launches": dom["n"], "avg_launch_us": dom["ms"] * 1e3 / dom["n"],
                     "share_of_gpu_time": dom["ms"] / total_ms}
         line = {
-            "metric": "generated jets/sec @128 particles, 100 steps", "value": value, "unit": "jets/s",
+            "metric": f"generated jets/sec @128 particles, {args.solver_steps} steps", "value": value, "unit": "jets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -114,6 +114,38 @@ __device__ inline int telegraph_draw_fast(float w_t1, float w_0t, float invV, in
   return cnt < V ? cnt : V - 1;
 }
 
+// The same posterior drawn in O(1): it has only three classes -- v = k1, v = k0 (when k0 != k1) and the
+// V-1 or V-2 "other" states of equal weight -- so one uniform picks the class and, inside "other",
+// the state.  (The order in which the CDF visits the states is irrelevant for the law of k_t.)
+struct TelegraphDrawCtx {
+  float base, e_same, e_k1, e_k0, rbase;   // a0*b0 ; extra weights ; 1/base
+  int V;
+};
+__device__ inline TelegraphDrawCtx telegraph_ctx(float w_t1, float w_0t, float invV, int V) {
+  const float a0 = invV - w_t1 * invV, a1 = a0 + w_t1;
+  const float b0 = invV - w_0t * invV, b1 = b0 + w_0t;
+  const float base = a0 * b0;
+  return TelegraphDrawCtx{base, a1 * b1 - base, a1 * b0 - base, a0 * b1 - base, __builtin_amdgcn_rcpf(base), V};
+}
+__device__ inline int telegraph_draw_o1(const TelegraphDrawCtx& c, int k0, int k1, float u) {
+  const bool same = k0 == k1;
+  const float wb = c.base + (same ? c.e_same : c.e_k1);          // weight of v = k1
+  const float wa = same ? 0.0f : c.base + c.e_k0;                // weight of v = k0 (k0 != k1)
+  const int n_other = c.V - (same ? 1 : 2);
+  float thr = u * (wb + wa + c.base * (float)n_other);
+  if (thr < wb) return k1;
+  thr -= wb;
+  if (thr < wa) return k0;
+  thr -= wa;
+  int idx = (int)(thr * c.rbase);
+  idx = idx < n_other - 1 ? idx : n_other - 1;
+  const int lo = k0 < k1 ? k0 : k1, hi = k0 < k1 ? k1 : k0;
+  int v = idx;
+  v += (v >= lo) ? 1 : 0;
+  v += (!same && v >= hi) ? 1 : 0;
+  return v;
+}
+
 // per-jet time draw t = eps + (1-eps) U  (multimodal_bridge_matching.py:202); its own tiny launch so
 // that the per-particle kernel does not repeat a Philox call (32-bit multiplies are quarter rate)
 __global__ void __launch_bounds__(256)
@@ -201,16 +233,20 @@ bridge_sample_rng4_kernel(int P4, int N, int V, const float* __restrict__ x1, co
       const longlong2 a = ks[0], b = ks[1];
       k1v[0] = a.x; k1v[1] = a.y; k1v[2] = b.x; k1v[3] = b.y;
     }
+    // N % 4 == 0 (host-checked): the four particles of a lane belong to ONE jet -> per-jet terms once
+    const float t = t_in[p0 / N];
+    const float std = bridge_std(bridge_kind, sigma, t), omt = 1.0f - t;
+    TelegraphDrawCtx tc;
+    if (k1 != nullptr)
+      tc = telegraph_ctx(thermo_w_fast(thermo_kind, c, t, 1.0f), thermo_w_fast(thermo_kind, c, 0.0f, t), invV, V);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int p = p0 + j;
-      const float t = t_in[p / N];
       uint32_t r[4];
       philox4<7>(seed, offset, (uint64_t)p, 1u, r);
       const float uk = u01(r[0]);
-      const int k0i = (int)(r[1] % (uint32_t)V);
+      const int k0i = (int)__umulhi(r[1], (uint32_t)V);            // uniform on {0..V-1}
       if (x1 != nullptr) {
-        const float std = bridge_std(bridge_kind, sigma, t), omt = 1.0f - t;
         float a0, a1, z0, z1, s2, z2;
         box_muller_fast(r[2], r[3], a0, a1);
         uint32_t q[4];
@@ -223,10 +259,8 @@ bridge_sample_rng4_kernel(int P4, int N, int V, const float* __restrict__ x1, co
         xtv[3 * j + 2] = (t * xs[3 * j + 2] + omt * s2) + std * z2;
       }
       if (k1 != nullptr) {
-        const float w_t1 = thermo_w_fast(thermo_kind, c, t, 1.0f);
-        const float w_0t = thermo_w_fast(thermo_kind, c, 0.0f, t);
         k0v[j] = k0i;
-        ktv[j] = telegraph_draw_fast(w_t1, w_0t, invV, V, k0i, (int)k1v[j], uk);
+        ktv[j] = telegraph_draw_o1(tc, k0i, (int)k1v[j], uk);
       }
     }
     if (x1 != nullptr) {
@@ -324,7 +358,7 @@ extern "C" int mmb_bridge_sample_rng(int B, int N, int Dc, int V, float eps, con
   hipLaunchKernelGGL(draw_time_kernel, dim3((B + 255) / 256), dim3(256), 0, as_stream(stream), B, eps, seed, offset,
                      t_out);
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  const bool fast4 = (P % 4 == 0) && (!x1 || (Dc == 3 && al16(x1) && al16(x0_out) && al16(xt))) &&
+  const bool fast4 = (P % 4 == 0) && (N % 4 == 0) && (!x1 || (Dc == 3 && al16(x1) && al16(x0_out) && al16(xt))) &&
                      (!k1 || (al16(k1) && al16(kt) && (!k0_out || al16(k0_out))));
   if (fast4)
     hipLaunchKernelGGL(bridge_sample_rng4_kernel, dim3(stream_grid(P / 4, 256)), dim3(256), 0, as_stream(stream),

@@ -125,7 +125,15 @@ def cpu_baseline(model, config, workload, n_jets, n_steps):
                       f"(source sampling included), {dt:.1f} s measured, scaled to the full grid"}
 
 
+def trace(msg):
+    if os.environ.get("MMB_BENCH_TRACE"):
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
+    if os.environ.get("MMB_BENCH_TRACE"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["MMB_BENCH_TRACE"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -144,14 +152,22 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)            # (rehearsals put several ranks on one card; the driver never does)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("MMB_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm; gloo only for rehearsal
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
+    trace("process group up")
     model, config = build_model(args.workload, args.solver_steps, device)
+    trace("model built")
     args.solver_steps = config.model.num_timesteps
     model.eval()
     model.manual_seed(0xA0A0, rank)
@@ -164,7 +180,9 @@ def main():
 
     for _ in range(args.warmup):
         one_generation(model, config, B, device)
+    trace("warm-up done")
     barrier()
+    trace("barrier passed")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_generation(model, config, B, device)
@@ -176,6 +194,7 @@ def main():
         elapsed = float(tt.item())
     jets = B * world * args.steps
     value = jets / elapsed
+    trace("generation timed")
 
     training = None
     if not args.no_train:

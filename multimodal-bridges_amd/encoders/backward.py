@@ -122,7 +122,16 @@ def _produced(tape):
     return keys
 
 
-def _linear_bwd(e, store, produced, mi, seed, arena):
+def _direct(p, touched):
+    """The parameter's existing .grad buffer when this backward may OVERWRITE it: first contribution of
+    this pass and a contiguous pre-zeroed buffer (the flat all-reduce bucket) -- saves an add per parameter."""
+    if p.grad is None or id(p) in touched or not p.grad.is_contiguous():
+        return None
+    touched.add(id(p))
+    return p.grad.view(-1)
+
+
+def _linear_bwd(e, store, produced, mi, seed, arena, touched):
     _, layer, N, segs, act, res1, post, res2, pre, y1, y2, p, off = e
     gY1, gY2 = store.get(y1), store.get(y2)
     if gY1 is None and gY2 is None:
@@ -167,11 +176,13 @@ def _linear_bwd(e, store, produced, mi, seed, arena):
             ops.grad_weight_rows(t, Sm, dWs, None)
         koff += Ks
     roff, rlen = layer._row_tables(W.device)
-    dv, dg, db = ops.weight_norm_bwd_rep(roff, rlen, layer.weight_v.detach().reshape(-1),
-                                         layer.weight_g.detach().reshape(-1), inv, dWr, dbr)
-    _acc_param(layer.weight_v, dv)
-    _acc_param(layer.weight_g, dg)
-    _acc_param(layer.bias, db)
+    prm = (layer.weight_v, layer.weight_g, layer.bias)
+    outs = tuple(_direct(q, touched) for q in prm)
+    res = ops.weight_norm_bwd_rep(roff, rlen, layer.weight_v.detach().reshape(-1),
+                                  layer.weight_g.detach().reshape(-1), inv, dWr, dbr, out=outs)
+    for q, o, r in zip(prm, outs, res):
+        if o is None:                                   # no pre-zeroed bucket (or a second use): accumulate
+            _acc_param(q, r)
     # ---- inputs
     need = [GradStore._key(t) in produced for t, _ in segs]
     if not any(need):
@@ -236,10 +247,11 @@ def run_backward(model, tape, heads, d_hc, d_hd, d_s=None, scale=None):
     seed = model.seed
     n_acc = sum(GW_REPLICAS * (e[1].weight_v.numel() + e[1].weight_v.shape[0] + 8) for e in tape if e[0] == "linear")
     arena = Arena(n_acc, mi.maskf.device)
+    touched = set()
     for e in reversed(tape):
         kind = e[0]
         if kind == "linear":
-            _linear_bwd(e, store, produced, mi, seed, arena)
+            _linear_bwd(e, store, produced, mi, seed, arena, touched)
         elif kind == "pool":
             gP = store.get(e[2])
             if gP is not None and GradStore._key(e[1]) in produced:

@@ -393,11 +393,13 @@ def grad_weight_rows(X, dZ, dW, db=None, replicas=1, rep_stride=0, db_stride=0):
          db_stride, stream())
 
 
-def weight_norm_bwd_rep(row_off, row_len, v_flat, g_flat, inv, dW_rep, db_rep):
-    """dW_rep (R, Nout*K) and db_rep (R, Nout) replicas -> (dv, dg, db)"""
-    dv = torch.empty_like(v_flat)
-    dg = torch.empty_like(g_flat)
-    db = torch.empty(g_flat.numel(), dtype=torch.float32, device=v_flat.device)
+def weight_norm_bwd_rep(row_off, row_len, v_flat, g_flat, inv, dW_rep, db_rep, out=None):
+    """dW_rep (R, Nout*K) and db_rep (R, Nout) replicas -> (dv, dg, db); out = (dv, dg, db) flat contiguous
+    buffers to overwrite (e.g. views of the flat gradient bucket), any of them None to allocate."""
+    dv, dg, db = out if out is not None else (None, None, None)
+    dv = torch.empty_like(v_flat) if dv is None else dv
+    dg = torch.empty_like(g_flat) if dg is None else dg
+    db = torch.empty(g_flat.numel(), dtype=torch.float32, device=v_flat.device) if db is None else db
     call("mmb_weight_norm_bwd_rep", g_flat.numel(), i32(row_off), i32(row_len), f32(v_flat), f32(g_flat), f32(inv),
          f32(dW_rep), dW_rep.shape[0], dW_rep.stride(0), f32(db_rep), db_rep.stride(0), f32(dv), f32(dg), f32(db),
          stream())

@@ -48,7 +48,12 @@ class FlatGrads:
 
     def all_reduce_mean(self, dist, world):
         if dist is not None and world > 1:
-            dist.all_reduce(self.flat)
+            if dist.get_backend() == "gloo" and self.flat.is_cuda:     # rehearsal only: gloo on device
+                host = self.flat.cpu()                                 # tensors is unreliable on ROCm
+                dist.all_reduce(host)
+                self.flat.copy_(host)
+            else:
+                dist.all_reduce(self.flat)
             self.flat.div_(world)
 
     def clip_(self, max_norm):

@@ -79,6 +79,35 @@ __device__ inline float fetch_cat(const Segs& sg, int row, int jet, float m, int
   return 0.0f;
 }
 
+// common epilogue of one 32x32 accumulator tile (C/D layout of 32x32x2: col = lane&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)):  y1 = act(z + b) + res1 [* row_scale];  y2 = dropout(post(y1)) + res2
+__device__ __forceinline__ void epilogue_tile(const f32x16& acc, int row0, int col, int half, int M, int Nout,
+                                              const float* __restrict__ bias, int act,
+                                              const float* __restrict__ residual, int64_t res_ld,
+                                              const float* __restrict__ row_scale, float* __restrict__ Y,
+                                              int64_t y_ld, float* __restrict__ pre_act, const Post& post) {
+  const bool col_ok = col < Nout;
+  const float bv = (bias && col_ok) ? bias[col] : 0.0f;
+  static_for<16>([&](auto ic) {
+    constexpr int i = decltype(ic)::v;
+    const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+    if (col_ok && row < M) {
+      float z = acc[i] + bv;
+      if (pre_act) pre_act[(int64_t)row * Nout + col] = z;
+      float y = apply_act(act, z);
+      if (residual) y += residual[(int64_t)row * res_ld + col];
+      if (row_scale) y *= row_scale[row];
+      if (Y) Y[(int64_t)row * y_ld + col] = y;
+      if (post.Y2) {
+        float y2 = apply_act(post.act, y);
+        if (post.drop_p > 0.0f) y2 = dropout_apply(y2, post.drop_p, post.seed, post.offset, (uint64_t)row * Nout + col);
+        if (post.res2) y2 += post.res2[(int64_t)row * post.res2_ld + col];
+        post.Y2[(int64_t)row * post.y2_ld + col] = y2;
+      }
+    }
+  });
+}
+
 template <int WAVES, int NT, int BK, bool ALIGNED>
 __global__ void __launch_bounds__(WAVES * 64)
 linear_cat_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restrict__ maskf,
@@ -224,28 +253,60 @@ linear_cat_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restri
   // epilogue.  C/D layout of 32x32x2: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   static_for<NT>([&](auto jc) {
     constexpr int j = decltype(jc)::v;
-    const int col = col0 + j * 32 + r32;
-    const bool col_ok = col < Nout;
-    const float bv = (bias && col_ok) ? bias[col] : 0.0f;
-    static_for<16>([&](auto ic) {
-      constexpr int i = decltype(ic)::v;
-      const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * half;
-      if (col_ok && row < M) {
-        float z = acc[j][i] + bv;
-        if (pre_act) pre_act[(int64_t)row * Nout + col] = z;
-        float y = apply_act(act, z);
-        if (residual) y += residual[(int64_t)row * res_ld + col];
-        if (row_scale) y *= row_scale[row];
-        if (Y) Y[(int64_t)row * y_ld + col] = y;
-        if (post.Y2) {
-          float y2 = apply_act(post.act, y);
-          if (post.drop_p > 0.0f) y2 = dropout_apply(y2, post.drop_p, post.seed, post.offset, (uint64_t)row * Nout + col);
-          if (post.res2) y2 += post.res2[(int64_t)row * post.res2_ld + col];
-          post.Y2[(int64_t)row * post.y2_ld + col] = y2;
-        }
-      }
-    });
+    epilogue_tile(acc[j], row0, col0 + j * 32 + r32, half, M, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld,
+                  pre_act, post);
   });
+}
+
+// ---- small-M variant (per-jet layers, M = B rows): split-K over the 4 waves of a block ----------
+// A per-jet layer is a (B x K) x (K x Nout) product with B ~ 1024: a handful of 32x32 tiles whose cost
+// is the LENGTH of the serial k loop, not flops.  Here one block owns ONE 32x32 output tile and its
+// four waves each take a quarter of K; both operands go straight from global memory to the MFMA
+// fragments with every load of the wave in flight at once (k is permuted inside the wave's slice so
+// that each lane reads one contiguous run of X[row][.] / W[col][.]), the four partial tiles meet in
+// LDS and wave 0 runs the common epilogue.  One ROW segment, K % 4 == 0, 16-byte aligned rows.
+template <int RL4>                                   // float4 per lane and operand: slice = 8*RL4 k values
+__global__ void __launch_bounds__(256)
+linear_splitk_kernel(int M, const float* __restrict__ X, int64_t x_ld, int K, const float* __restrict__ W,
+                     int64_t w_ld, const float* __restrict__ bias, int Nout, int act,
+                     const float* __restrict__ residual, int64_t res_ld, const float* __restrict__ row_scale,
+                     float* __restrict__ Y, int64_t y_ld, float* __restrict__ pre_act, Post post) {
+  constexpr int RL = 4 * RL4;                        // contiguous floats per lane
+  __shared__ float red[3][16 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r32 = lane & 31;
+  const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
+  const int row = min(row0 + r32, M - 1), col = min(col0 + r32, Nout - 1);      // clamped loads, guarded stores
+  const int kb = wave * (2 * RL) + half * RL;        // this lane's run inside the block's K range
+  const float* xp = X + (int64_t)row * x_ld + kb;
+  const float* wp = W + (int64_t)col * w_ld + kb;
+  float4 a[RL4], b[RL4];
+#pragma unroll
+  for (int q = 0; q < RL4; ++q) {
+    const bool ok = kb + 4 * q < K;                  // K % 4 == 0: a float4 is all in or all out
+    a[q] = ok ? *reinterpret_cast<const float4*>(xp + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    b[q] = ok ? *reinterpret_cast<const float4*>(wp + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+  for (int q = 0; q < RL4; ++q) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b[q].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b[q].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b[q].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b[q].w, acc, 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave - 1][i * 64 + lane] = acc[i];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += (red[0][i * 64 + lane] + red[1][i * 64 + lane]) + red[2][i * 64 + lane];
+    epilogue_tile(acc, row0, col0 + r32, half, M, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld, pre_act,
+                  post);
+  }
 }
 
 // ---------------------------------------------------------------- weight norm ----------
@@ -427,6 +488,30 @@ extern "C" int mmb_linear_cat(int M, int rows_per_jet, int n_seg, const void* co
   al16 = al16 && w_al;
   al8 = al8 && w_al;
   hipStream_t st = as_stream(stream);
+  // per-jet layers (one ROW segment, few rows): split-K kernel, one 32x32 tile per block
+  const bool al4 = (seg_ld[0] % 4 == 0) && ((reinterpret_cast<uintptr_t>(seg_ptr[0]) & 15) == 0) && w_al;
+  if (M <= 4096 && n_seg == 1 && seg_kind[0] == MMB_SEG_ROW && K % 4 == 0 && K <= 8 * 4 * 12 && al4) {
+    const int rl4 = (K + 31) / 32;                 // float4 per lane: 4 waves x 2 halves x 4 floats
+    dim3 g2((M + 31) / 32, (Nout + 31) / 32);
+    const float* Xp = (const float*)seg_ptr[0];
+#define MMB_SK(R_) hipLaunchKernelGGL((linear_splitk_kernel<R_>), g2, dim3(256), 0, st, M, Xp, (int64_t)seg_ld[0], K, W, w_ld, bias, Nout, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post)
+    switch (rl4) {
+      case 1: MMB_SK(1); break;
+      case 2: MMB_SK(2); break;
+      case 3: MMB_SK(3); break;
+      case 4: MMB_SK(4); break;
+      case 5: MMB_SK(5); break;
+      case 6: MMB_SK(6); break;
+      case 7: MMB_SK(7); break;
+      case 8: MMB_SK(8); break;
+      case 9: MMB_SK(9); break;
+      case 10: MMB_SK(10); break;
+      case 11: MMB_SK(11); break;
+      default: MMB_SK(12); break;
+    }
+#undef MMB_SK
+    return check_launch("mmb_linear_cat");
+  }
   const bool small_m = M <= 4096;                // per-jet rows: one wave per block for parallelism
   const int nt = Nout <= 32 ? 1 : (Nout <= 64 ? 2 : 4);
   const int bm = small_m ? 32 : 128;

@@ -171,6 +171,11 @@ def test_loss_fwd_bwd(ops):
     (1024 * 8, 128, [32, 128, 32], [2, 0, 1], 128, "lrelu"),     # 4-wave blocks, NT=4
     (5000, 50, [48], [0], 3, None),                              # head-like, ragged M
     (64, 1, [160, 16], [0, 0], 64, "gelu"),                      # per-jet rows
+    (1024, 1, [144], [0], 64, "lrelu"),                          # per-jet split-K kernel (fc_glob1, S3 branch)
+    (1000, 1, [288], [0], 128, "lrelu"),                         # split-K, ragged M, widest K
+    (300, 1, [20], [0], 8, None),                                # split-K, K below one slice, ragged Nout
+    (1024, 1, [384], [0], 128, "gelu"),                          # split-K upper limit (S2 projection)
+    (512, 1, [400], [0], 16, None),                              # beyond the split-K limit: layered small-M path
 ])
 def test_linear_cat(ops, M, N, widths, kinds, Nout, act):
     g = torch.Generator().manual_seed(M + Nout)

@@ -41,6 +41,31 @@ def main():
     for n, v in sorted(res.items(), key=lambda kv: -kv[1]):
         print(f"  {n:12s} {v:12d}  {100.0 * v / max(tot, 1):5.1f} %")
     print(json.dumps(res))
+    if hasattr(lib, "mmb_debug_fused_map"):
+        nb = min(B, 512)
+        mp = (ctypes.c_uint * (nb * 4))()
+        lib.mmb_debug_fused_map.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.mmb_debug_fused_map(mp, nb * 4)
+        # HW_ID (gfx9): wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh[12] se[15:13]; XCC_ID[3:0] in the high half
+        where = {}
+        for blk in range(nb):
+            ws = [mp[blk * 4 + w] for w in range(4)]
+            simd = [(v >> 4) & 3 for v in ws]
+            cu = ((ws[0] >> 8) & 15, (ws[0] >> 12) & 1, (ws[0] >> 13) & 7, (ws[0] >> 16) & 15)
+            where.setdefault(cu, []).append((blk, simd))
+        shown = 0
+        for cu, lst in sorted(where.items()):
+            if shown < 12:
+                print("CU(cu,sh,se,xcc)=", cu, lst)
+                shown += 1
+        import collections
+        print("blocks per CU histogram:", collections.Counter(len(v) for v in where.values()))
+        print("wave->simd patterns:", collections.Counter(tuple(sd) for v in where.values() for _, sd in v).most_common(6))
+        d = collections.Counter()
+        for v in where.values():
+            if len(v) == 2:
+                d[abs(v[0][0] - v[1][0])] += 1
+        print("block-index distance of co-resident pairs:", d.most_common(8))
 
 
 if __name__ == "__main__":

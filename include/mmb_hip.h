@@ -109,6 +109,13 @@ int mmb_telegraph_probs(int B, int N, int V, const float* t, const int64_t* k0, 
 int mmb_bridge_drift(int B, int N, int Dc, const float* t, const float* xt, const float* x0,
                      const float* x1, int bridge_kind, float* out, void* stream);
 
+/* Generation post-processing, in place (pipeline/callbacks_generator.py:99-128 + TensorMultiModal.apply_mask,
+ * tensorclass.py:96-106): x = x*scale[d] + shift[d] (scale/shift of length Dc, both NULL for no transform:
+ * "standardize" -> std/mean, "normalize" -> (max-min)/min), log_pt != 0 additionally x[...,0] = exp(x[...,0]) - 1e-6;
+ * then x *= mask and k = (k*mask).long().  x (P,Dc) | NULL, k (P) | NULL, maskf (P) f32. */
+int mmb_postprocess(int64_t P, int Dc, float* x, int64_t* k, const float* maskf, const float* scale,
+                    const float* shift, int log_pt, void* stream);
+
 /* ---------------------------------------------------------------- K-B continuous solver */
 
 /* ContinuousSolver.euler_step (solvers.py:21-25): x += dt*v, in place, n = B*N*Dc floats */

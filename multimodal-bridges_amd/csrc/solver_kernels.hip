@@ -208,9 +208,45 @@ static int launch_jump(const char* name, int B, int N, int V, const float* logit
   return check_launch(name);
 }
 
+// ------------------------------------------------------------------ post-processing ----
+// Generation post-processing (pipeline/callbacks_generator.py:99-128): inverse of the data
+// transform -- x*scale + shift per feature, for "log_pt" additionally x[0] = exp(x[0]) - 1e-6 --
+// followed by TensorMultiModal.apply_mask (tensorclass.py:96-106): x *= mask, k = (k*mask).long().
+// One lane per particle, in place; 2*(4 Dc + 8) + 4 B/particle.
+__global__ void __launch_bounds__(256)
+postprocess_kernel(int64_t P, int Dc, float* __restrict__ x, int64_t* __restrict__ k,
+                   const float* __restrict__ maskf, const float* __restrict__ scale,
+                   const float* __restrict__ shift, int log_pt) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+    const float m = maskf[p];
+    if (x != nullptr) {
+      float* xp = x + p * Dc;
+      for (int d = 0; d < Dc; ++d) {
+        float v = xp[d];
+        if (scale != nullptr) v = v * scale[d] + shift[d];
+        if (log_pt && d == 0) v = expf(v) - 1e-6f;
+        xp[d] = v * m;
+      }
+    }
+    if (k != nullptr) k[p] = (int64_t)((float)k[p] * m);           // (discrete * mask).long(): truncation toward zero
+  }
+}
+
 }  // namespace mmb
 
 using namespace mmb;
+
+extern "C" int mmb_postprocess(int64_t P, int Dc, float* x, int64_t* k, const float* maskf, const float* scale,
+                               const float* shift, int log_pt, void* stream) {
+  MMB_REQUIRE(P > 0, "mmb_postprocess: empty batch");
+  MMB_REQUIRE(maskf && (x || k), "mmb_postprocess: NULL argument");
+  if (x) MMB_REQUIRE(Dc > 0, "mmb_postprocess: Dc=%d", Dc);
+  MMB_REQUIRE((scale == nullptr) == (shift == nullptr), "mmb_postprocess: scale and shift go together");
+  if (log_pt) MMB_REQUIRE(scale, "mmb_postprocess: log_pt needs the standardisation statistics");
+  hipLaunchKernelGGL(postprocess_kernel, dim3(stream_grid(P, 256)), dim3(256), 0, as_stream(stream), P, Dc, x, k,
+                     maskf, scale, shift, log_pt);
+  return check_launch("mmb_postprocess");
+}
 
 extern "C" int mmb_euler_step(int64_t n, float* x, const float* v, float dt, void* stream) {
   MMB_REQUIRE(n > 0, "mmb_euler_step: n=%lld", (long long)n);

@@ -404,3 +404,11 @@ def weight_norm_bwd_rep(row_off, row_len, v_flat, g_flat, inv, dW_rep, db_rep, o
          f32(dW_rep), dW_rep.shape[0], dW_rep.stride(0), f32(db_rep), db_rep.stride(0), f32(dv), f32(dg), f32(db),
          stream())
     return dv, dg, db
+
+
+def postprocess_(x, k, maskf, scale=None, shift=None, log_pt=False):
+    """In-place inverse data transform + apply_mask on a generated sample (x (..,Dc) | None, k (..,1) | None)."""
+    P = maskf.numel()
+    Dc = x.shape[-1] if x is not None else 0
+    call("mmb_postprocess", P, Dc, f32(x, "x"), i64(k, "k"), f32(maskf, "maskf"), f32(scale, "scale"),
+         f32(shift, "shift"), int(bool(log_pt)), stream())

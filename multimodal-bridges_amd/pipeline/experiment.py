@@ -189,8 +189,10 @@ class ExperimentPipeline:
 
     # ------------------------------------------------------------------ generation
     @torch.no_grad()
-    def generate(self, gather=True):
-        """Each rank generates its shard of the test jets; rank 0 receives the concatenation."""
+    def generate(self, gather=True, postprocess=True):
+        """Each rank generates its shard of the test jets, inverts the data transform and applies the mask on
+        the device (pipeline/postprocess.py; reference GeneratorCallback._postprocess); rank 0 receives the
+        concatenation."""
         model = self.model.eval()
         self.datamodule.setup("predict", rank=self.rank, world=self.world, device=self.device)
         outs = []
@@ -198,6 +200,15 @@ class ExperimentPipeline:
             paths, _ = model.predict_step(batch, i, to_cpu=False)
             outs.append(paths[1])
         gen = TensorMultiModal.cat(outs, dim=0)
+        if postprocess:
+            from pipeline.postprocess import postprocess as _post
+            transform = getattr(self.config.data, "transform", None)
+            metadata = None
+            if transform is not None:                     # statistics written next to the checkpoints at training time
+                import json
+                with open(os.path.join(self.experiment_path, "metadata.json")) as fh:
+                    metadata = json.load(fh)
+            gen = _post(gen, transform, metadata, getattr(self.config.data, "discrete_features", "tokens"))
         if gather and self.dist is not None:
             parts = [None] * self.world
             self.dist.all_gather_object(parts, gen.cpu())

@@ -338,3 +338,25 @@ def test_grad_weight_rows(ops, M, K, Nout, x_pad):
     close(dW.double() - 0.25, want, rtol=1e-4, atol=2e-5 * scale)
     close(db.double() + 1.0, dZ.double().sum(0), rtol=1e-4, atol=2e-5 * float(dZ.abs().sum(0).max()))
     assert float((wide[:, :2] - 0.25).abs().max()) == 0.0 and float((wide[:, 2 + K:] - 0.25).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("transform", [None, "standardize", "normalize", "log_pt"])
+def test_postprocess(ops, transform):
+    """Device post-processing against the CPU restatement of the reference's _postprocess + apply_mask."""
+    from oracle.postprocess import postprocess as ref_post
+    from pipeline.postprocess import postprocess
+    from tensorclass import TensorMultiModal
+    g = torch.Generator().manual_seed(5)
+    B, N = 37, 50
+    x = torch.randn(B, N, 3, generator=g)
+    k = torch.randint(0, 8, (B, N, 1), generator=g)
+    mask = (torch.rand(B, N, 1, generator=g) > 0.4).long()
+    stats = {"mean": [1.5, -0.2, 0.1], "std": [0.7, 0.3, 0.25], "min": [-3.0, -1.0, -1.2], "max": [4.0, 1.1, 0.9]}
+    want_x, want_k = ref_post(x, k, mask, transform, stats)
+    paths = TensorMultiModal(None, dev(x), dev(k), dev(mask))
+    out = postprocess(paths, transform, {"target": stats})
+    close(out.continuous, want_x, rtol=1e-5, atol=1e-6)
+    assert torch.equal(out.discrete.cpu(), want_k) and out.discrete.dtype == torch.int64
+    # discrete-only sample
+    out2 = postprocess(TensorMultiModal(None, None, dev(k), dev(mask)), None, None)
+    assert torch.equal(out2.discrete.cpu(), want_k)

@@ -295,6 +295,38 @@ int mmb_fused_epic_forward(int variant, int B, int N, const float* packed, const
                            const float* x, const int64_t* k, const float* temb, int64_t temb_stride,
                            int which, float* head_c, float* head_d, void* stream);
 
+/* The same forward in TRAINING mode (the encoder call of training_step, multimodal_bridge_matching.py:108-121):
+ * both heads, the inverted dropout of EPiCLayer (epic.py:196-206; Philox keep-mask indexed like mmb_linear_cat's,
+ * offsets offset0+1, +2, ... in execution order) and every activation the reverse pass reads, written row-major
+ * from the accumulator registers.  slots: device array of n_slots records {float* p; int64 ld; int64 n}
+ * (destination, row pitch, floats available from p) in execution order: per branch [projection: local.0 pre/out,
+ * local.2 pre/out, pooled, global.0 pre/out, global.2 pre/out; per layer: pooled, fc_glob1 out, g', g_out, fc_loc1
+ * out, l_out; output], the concatenated global vector, fused encoder [layers; output], heads [.0 pre/out] x 2.
+ * head_c (B*N,3), head_d (B*N,8). */
+int mmb_fused_epic_train_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
+                                 int nb_branch, int nb_fused_exec, int use_skip,
+                                 int off_cw, int off_cb, int off_table,
+                                 const float* maskf, const int32_t* counts,
+                                 const float* x, const int64_t* k, const float* temb, int64_t temb_stride,
+                                 const void* slots, int n_slots, float drop_p, uint64_t seed, uint64_t offset0,
+                                 float* head_c, float* head_d, void* stream);
+
+/* Reverse pass of that forward for every jet in ONE launch (what loss.backward() does to the encoder in the
+ * reference's training_step): gradients of activations stay in registers; the kernel reads the saved activations and
+ * writes, row-major, the dZ of every weight-normed Linear plus the per-jet column sums of dZ (gradients of the
+ * broadcast time / global-vector inputs) -- the operands of mmb_grad_weight_rows -- and d temb (B,Et).
+ * packed_bwd/desc_bwd: mmb_hip.fused.packed_bwd (transposed x-parts in fragment order).  slots: records as above:
+ * [0] d f (rows,2Hb) [1] d h from the heads (rows,2Hb) [2] d cat[h1,h2] (rows,2Hb) [3] d temb (B,Et), then per head
+ * {d head, .0 pre, .0 dZ, column sums}, fused encoder {column sums of the output layer; per layer, last first:
+ * l_out, [skip], fc_loc2 dZ, fc_loc1 out, fc_loc1 dZ, its column sums, g', fc_glob2 dZ, fc_glob1 out, fc_glob1 dZ},
+ * per branch the same followed by the projection {global.2 pre, dZ, global.0 pre, dZ, local.2 pre, dZ, local.0 pre,
+ * dZ, column sums} and, for the continuous branch, d (continuous embedding) (rows,Ec). */
+int mmb_fused_epic_train_backward(int variant, int B, int N, const float* packed_bwd, const int32_t* desc_bwd,
+                                  int nb_branch, int nb_fused_exec, int use_skip,
+                                  const float* maskf, const int32_t* counts,
+                                  const void* slots, int n_slots, float drop_p, uint64_t seed, uint64_t offset0,
+                                  void* stream);
+
 /* simulate_dynamics (multimodal_bridge_matching.py:227-259) in ONE launch: per grid point
  * [forward -> Euler step on x (solvers.py:21-25)] [forward -> telegraph rates (bridges.py:137-163)
  * -> tau-leap jump (solvers.py:59-81)], final k = argmax of the last rates.  x (B,N,3) and k (B,N)

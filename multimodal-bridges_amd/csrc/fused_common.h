@@ -1,0 +1,454 @@
+// Building blocks of the fused per-jet EPiC kernels (fused_epic.hip: forward / generation,
+// fused_epic_bwd.hip: training backward): register-resident transposed activations in the C/D layout of
+// v_mfma_f32_32x32x2_f32, packed A-operand weight fragments fetched with buffer loads, per-jet
+// matvecs, butterfly pooling, and the row-major save/load slots of the training path.
+#pragma once
+#include "common.h"
+#include <utility>
+
+namespace mmb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int I> struct IF { static constexpr int v = I; };
+template <typename F, int... Is>
+__device__ __forceinline__ void ffor_impl(F&& f, std::integer_sequence<int, Is...>) { (f(IF<Is>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void ffor(F&& f) { ffor_impl(f, std::make_integer_sequence<int, N>{}); }
+
+constexpr int FE_THREADS = 256;
+
+
+// ------------------------------------------------------------------ small helpers ------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+// sum over the 32 lanes that share (lane >> 5); every lane of the half ends up with the sum
+__device__ __forceinline__ float half_sum32(float v) {
+  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]  (xor 1)
+  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]  (xor 2)
+  v += dpp_mov<0x141>(v);    // row_half_mirror      (other quad of the 8)
+  v += dpp_mov<0x140>(v);    // row_mirror           (other 8 of the 16)
+  v += __shfl_xor(v, 16, 64);
+  return v;
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float lrelu_f(float x) { return x > 0.0f ? x : 0.01f * x; }
+template <int ACT>
+__device__ __forceinline__ float act_f(float x) {
+  if constexpr (ACT == MMB_ACT_GELU) return gelu_f(x);
+  if constexpr (ACT == MMB_ACT_LRELU) return lrelu_f(x);
+  return x;
+}
+
+// per-layer descriptor: offsets (in floats) into the packed parameter buffer, -1 = absent
+struct LDesc {
+  int wx;   // MFMA part, packed [KT][4][OT][64][4]        (per-particle layers)
+  int wt;   // transposed [Kt][O]: time part (per-particle layers) or the whole W^T (per-jet layers)
+  int wg;   // transposed [G][O]: global-vector part
+  int b;    // bias [O] (padded to a multiple of 32 for per-particle layers)
+};
+
+struct alignas(16) Lds {
+  float temb[128];
+  float gcur[64], gskip[64], gnew[64], gcat[64];
+  float partial[4 * 128];
+  float gh[128];
+  float cvec[128], dvec[128];
+  float cw[32 * 4], cb[32];       // continuous embedding weight [Ec][Dc<=4], bias
+  float table[8 * 32];            // discrete embedding table [V<=8][Ed<=32]
+  float cnt;
+  int red[4];
+  float park[4][FE_THREADS];      // generation loop: x (3) and k of this lane's particle while a forward runs
+#ifdef MMB_FE_PROF
+  unsigned long long tlast;
+#endif
+};
+
+// exchange with the lane whose index differs in bit BIT
+template <int BIT>
+__device__ __forceinline__ float lane_xchg(float v) {
+  if constexpr (BIT == 0) return dpp_mov<0xB1>(v);            // quad_perm [1,0,3,2]
+  else if constexpr (BIT == 1) return dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+  else if constexpr (BIT == 3) return dpp_mov<0x128>(v);      // row_ror:8 == xor 8 inside a row of 16
+  else if constexpr (BIT == 2)
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x101F));   // xor 4
+  else if constexpr (BIT == 4)
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // xor 16
+  else return __shfl_xor(v, 32, 64);
+}
+
+constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x / 2); }
+
+// ---- training forward: every tensor the reverse pass needs goes to HBM (row-major, the layout of
+// the layered path's tape, encoders/backward.py) straight from the accumulator registers, and the
+// inverted dropout of epic.py:196-206 is applied with the layered path's Philox indexing.
+struct SaveSlot {
+  float* p;        // (rows, ld) row-major destination; rows = B*N (per-particle) or B (per-jet)
+  int64_t ld;      // row pitch in floats (a column slice of a wider buffer has ld > width)
+  int64_t n;       // floats available from p: stores are clipped to it whatever the slot order
+};
+struct NoTrain {
+  static constexpr bool on = false;
+};
+struct Train {
+  static constexpr bool on = true;
+  const SaveSlot* tab;
+  int n_slots, si;
+  int b, N, p;               // jet, particles per jet, this lane's particle
+  float drop_p;
+  uint64_t seed, off;
+
+  __device__ __forceinline__ SaveSlot next() {
+    const int i = si < n_slots ? si : n_slots - 1;
+    ++si;
+    return tab[i];
+  }
+  // HT tiles in C/D layout -> rows [b*N, b*N+N) of the slot; lanes of padded particles (p >= N) fall
+  // outside the buffer range and the hardware drops their stores
+  template <int HT>
+  __device__ __forceinline__ void tiles(const f32x16 (&x)[HT], int half) {
+    const SaveSlot s = next();
+    const int64_t base = (int64_t)b * N * s.ld;
+    int64_t room = s.n - base, want = (int64_t)N * s.ld;
+    room = room < want ? room : want;
+    room = room < 0 ? 0 : room;
+    const __amdgpu_buffer_rsrc_t R = __builtin_amdgcn_make_buffer_rsrc(s.p + base, 0, (int)(room * 4), 0x00020000);
+    const int vo = (p * (int)s.ld + 4 * half) * 4;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+      ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
+        const float4 v = make_float4(x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), R, vo, (32 * t + 8 * q) * 4, 0); }); });
+  }
+  // W floats of a per-jet vector (LDS) -> row b of the slot
+  __device__ __forceinline__ void vec(const float* v, int W, int tid) {
+    const SaveSlot s = next();
+    const int64_t i = (int64_t)b * s.ld + tid;
+    if (tid < W && i < s.n) s.p[i] = v[tid];
+  }
+  // row b of the next slot as a pointer for a producer that writes it itself (W floats), or NULL
+  __device__ __forceinline__ float* row(int W) {
+    const SaveSlot s = next();
+    const int64_t i = (int64_t)b * s.ld;
+    return i + W <= s.n ? s.p + i : nullptr;
+  }
+  __device__ __forceinline__ float keep(uint32_t r) const { return u01(r) < drop_p ? 0.0f : 1.0f / (1.0f - drop_p); }
+  __device__ __forceinline__ float drop(float v, uint32_t r) const { return u01(r) < drop_p ? 0.0f : v / (1.0f - drop_p); }
+};
+
+// ---- training backward: the same slot table, walked by a kernel that LOADS saved activations and
+// STORES the layer gradients dZ (row-major, consumed by the weight-gradient kernel) -------------
+struct Rows {                 // rows [b*N, b*N+N) of a per-particle slot seen from this lane
+  __amdgpu_buffer_rsrc_t R;
+  int vo;                     // byte offset of this lane's particle row + its lane-half column group
+};
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 load_tile(const Rows& r, int t) {
+  f32x16 v;
+  ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
+    const auto w = __builtin_amdgcn_raw_buffer_load_b128(r.R, r.vo, (32 * t + 8 * q) * 4, 0);
+    static_assert(sizeof(w) == 16, "b128 buffer load");
+    const float4 a = __builtin_bit_cast(float4, w);
+    v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w; });
+  return v;
+}
+__device__ __forceinline__ void store_tile(const Rows& r, int t, const f32x16& x) {
+  ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
+    const float4 v = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r.R, r.vo, (32 * t + 8 * q) * 4, 0); });
+}
+
+struct Slots {
+  const SaveSlot* tab;
+  int n_slots, si;
+  int b, N, p, half;
+
+  __device__ __forceinline__ SaveSlot at(int i) const { return tab[i < n_slots ? i : n_slots - 1]; }
+  __device__ __forceinline__ SaveSlot next() { return at(si++); }
+  // lanes of padded particles (p >= N) and anything past the slot's extent fall outside the buffer
+  // range: their loads return 0 and their stores are dropped by the hardware
+  __device__ __forceinline__ Rows rows_of(const SaveSlot& s, int col0 = 0) const {
+    const int64_t base = (int64_t)b * N * s.ld + col0;
+    int64_t room = s.n - base, want = (int64_t)N * s.ld - col0;
+    room = room < want ? room : want;
+    room = room < 0 ? 0 : room;
+    Rows r;
+    r.R = __builtin_amdgcn_make_buffer_rsrc(s.p + base, 0, (int)(room * 4), 0x00020000);
+    r.vo = (p * (int)s.ld + 4 * half) * 4;
+    return r;
+  }
+  __device__ __forceinline__ Rows rows() { return rows_of(next()); }
+  // row b of a per-jet slot (W floats) or NULL when it does not fit
+  __device__ __forceinline__ float* row_of(const SaveSlot& s, int W) const {
+    const int64_t i = (int64_t)b * s.ld;
+    return i + W <= s.n ? s.p + i : nullptr;
+  }
+  __device__ __forceinline__ float* row(int W) { return row_of(next(), W); }
+};
+
+// Per-jet matvec  out[o] = act( sum_k WT[k*O+o] v(k) + bias[o] ) + add[o]  with ONE barrier.
+// The O outputs are split over the 4 waves (OW each); inside a wave lane = part*G + og: og picks VW
+// consecutive outputs (one dwordx4/x2 per k), part picks every PARTS-th k.  The PARTS partial sums
+// live in lanes of the SAME wave and are folded with lane exchanges (no LDS round trip, no barrier);
+// the only barrier publishes `out` to the other waves.  vfn(k) yields the input element (LDS).
+template <int K, int O>
+struct WaveMV {
+  static_assert((O & (O - 1)) == 0 && O >= 8 && O <= 256, "WaveMV: O must be a power of two in [8,256]");
+  static constexpr int OW = O / 4;                       // outputs per wave
+  static constexpr int VW = OW >= 4 ? 4 : OW;            // outputs per lane
+  static constexpr int G = OW / VW;                      // lane groups along the outputs
+  static constexpr int PARTS = 64 / G;                   // k-partitions inside the wave
+  static constexpr int ITER = (K + PARTS - 1) / PARTS;
+  static constexpr bool RAGGED = (K % PARTS) != 0;
+  typedef float vec __attribute__((ext_vector_type(VW)));
+
+  template <int ACT, typename VFn>
+  static __device__ __forceinline__ void run(const float* __restrict__ WT, const float* __restrict__ bias, VFn&& vfn,
+                                             float* out, const float* add, int tid, float* pre = nullptr) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int og = lane & (G - 1), part = lane / G;
+    const int o0 = wave * OW + og * VW;
+    const vec* wp = reinterpret_cast<const vec*>(WT + o0);
+    vec bv;
+    ffor<VW>([&](auto ec) { bv[decltype(ec)::v] = 0.0f; });
+    if (bias != nullptr && part == 0) bv = *reinterpret_cast<const vec*>(bias + o0);
+    vec acc;
+    ffor<VW>([&](auto ec) { acc[decltype(ec)::v] = 0.0f; });
+    constexpr int UN = 12;                               // loads in flight per lane
+    ffor<(ITER + UN - 1) / UN>([&](auto cc) {
+      constexpr int c0 = decltype(cc)::v * UN;
+      constexpr int n = (ITER - c0) < UN ? (ITER - c0) : UN;
+      vec w[n];
+      ffor<n>([&](auto ic) {
+        constexpr int it = c0 + decltype(ic)::v;
+        int kk = part + it * PARTS;
+        if constexpr (RAGGED && it == ITER - 1) kk = kk < K ? kk : K - 1;
+        w[decltype(ic)::v] = wp[kk * (O / VW)];
+      });
+      ffor<n>([&](auto ic) {
+        constexpr int it = c0 + decltype(ic)::v;
+        const int kk = part + it * PARTS;
+        float vv;
+        if constexpr (RAGGED && it == ITER - 1) vv = kk < K ? vfn(kk) : 0.0f; else vv = vfn(kk);
+        acc += w[decltype(ic)::v] * vv;
+      });
+    });
+    // fold the PARTS partitions: lane bits log2(G) .. 5
+    ffor<6 - ilog2(G)>([&](auto bc) {
+      constexpr int bit = ilog2(G) + decltype(bc)::v;
+      ffor<VW>([&](auto ec) { constexpr int e = decltype(ec)::v; acc[e] += lane_xchg<bit>(acc[e]); });
+    });
+    if (part == 0) {
+      ffor<VW>([&](auto ec) {
+        constexpr int e = decltype(ec)::v;
+        if (pre) pre[o0 + e] = acc[e] + bv[e];
+        float t = act_f<ACT>(acc[e] + bv[e]);
+        if (add) t += add[o0 + e];
+        out[o0 + e] = t;
+      });
+    }
+    __syncthreads();
+  }
+};
+
+template <int ACT, int K, int O>
+__device__ __forceinline__ void matvec(const float* __restrict__ WT, const float* __restrict__ bias, const float* v,
+                                       float* out, const float* add, int tid, float* pre = nullptr) {
+  WaveMV<K, O>::template run<ACT>(WT, bias, [&](int k) { return v[k]; }, out, add, tid, pre);
+}
+
+// A lane's 16 values of tile t parked in / fetched from LDS: slot (t,q) holds one float4 per thread.
+__device__ __forceinline__ void park_tile(float4* S, int t, const f32x16& v, int tid) {
+  ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
+    S[(t * 4 + q) * FE_THREADS + tid] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]); });
+}
+__device__ __forceinline__ f32x16 fetch_tile(const float4* S, int t, int tid) {
+  f32x16 v;
+  ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
+    const float4 a = S[(t * 4 + q) * FE_THREADS + tid];
+    v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w; });
+  return v;
+}
+
+// Weight fragments are fetched with BUFFER loads: one descriptor for the packed parameter block
+// (SGPRs), the per-lane part of the address is the constant lane*16 in ONE VGPR, the fragment's
+// position is a wave-uniform SGPR offset -- no 64-bit per-load address arithmetic and no address
+// registers for the allocator to keep alive across the MFMA stream.
+typedef __amdgpu_buffer_rsrc_t WRsrc;
+__device__ __forceinline__ WRsrc weight_rsrc(const float* P) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, 0x7FFFFFFC, 0x00020000);
+}
+// float4 at packed float offset `woff` (uniform) + 64*f4 (uniform, float4 units) + this lane's float4
+__device__ __forceinline__ float4 wload(WRsrc R, int woff, int f4, int lane16) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(R, lane16, (woff + 4 * f4) * 4, 0);
+  static_assert(sizeof(v) == 16, "b128 buffer load");
+  return __builtin_bit_cast(float4, v);
+}
+
+// First A-operand group (k-steps 0..3 of every output tile) of a packed weight matrix, fetched
+// ahead of the GEMM that uses it -- while the previous GEMM or the per-jet chain runs -- so that no
+// GEMM starts with an exposed L2 round trip.
+template <int OT>
+struct AFrag {
+  float4 a[OT];
+};
+template <int OT>
+__device__ __forceinline__ void mma_prefetch(AFrag<OT>& f, WRsrc R, int woff, int lane) {
+  ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; f.a[ot] = wload(R, woff, ot * 64, lane * 16); });
+}
+
+// acc[ot] += W_x (tile rows ot) * X^T, X^T tiles delivered by `tile(IF<ft>)` (a reference to
+// registers, or a value fetched from LDS).  A-operand groups (4 k-steps x OT tiles, one dwordx4 per
+// lane and tile) run D groups ahead of the MFMAs through a ring of D+1 register buffers; D is
+// chosen so that the look-ahead is ~1000 MFMA cycles whatever OT is.
+template <int KT, int OT, typename TileFn>
+__device__ __forceinline__ void mma_x(f32x16 (&acc)[OT], TileFn&& tile, WRsrc R, int woff, int lane,
+                                      const AFrag<OT>& pre) {
+  constexpr int NG = KT * 4;
+  constexpr int D0 = OT >= 4 ? 1 : (OT == 2 ? 2 : 4);
+  constexpr int D = D0 < NG - 1 ? D0 : (NG - 1 > 0 ? NG - 1 : 1);
+  const int lane16 = lane * 16;
+  float4 ring[D + 1][OT];
+  ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; ring[0][ot] = pre.a[ot]; });
+  ffor<D - 1>([&](auto dc) {
+    constexpr int g = 1 + decltype(dc)::v;
+    if constexpr (g < NG)
+      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; ring[g][ot] = wload(R, woff, (g * OT + ot) * 64, lane16); });
+  });
+  ffor<KT>([&](auto fc) {
+    constexpr int ft = decltype(fc)::v;
+    decltype(auto) xt = tile(IF<ft>{});
+    ffor<4>([&](auto qc) {
+      constexpr int q = decltype(qc)::v;          // group = (ft, q): four k-steps r = 4q..4q+3
+      constexpr int g = ft * 4 + q;
+      constexpr int cur = g % (D + 1);
+      if constexpr (g + D < NG)
+        ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+          ring[(g + D) % (D + 1)][ot] = wload(R, woff, ((g + D) * OT + ot) * 64, lane16); });
+      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[cur][ot].x, xt[4 * q + 0], acc[ot], 0, 0, 0); });
+      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[cur][ot].y, xt[4 * q + 1], acc[ot], 0, 0, 0); });
+      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[cur][ot].z, xt[4 * q + 2], acc[ot], 0, 0, 0); });
+      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[cur][ot].w, xt[4 * q + 3], acc[ot], 0, 0, 0); });
+    });
+  });
+}
+
+// acc[ot][r] = m * c[f] + d[f]  (c, d in LDS or global; either may be null)
+template <int OT>
+__device__ __forceinline__ void acc_init(f32x16 (&acc)[OT], float m, const float* c, const float* d, int half) {
+  ffor<OT>([&](auto oc) {
+    constexpr int ot = decltype(oc)::v;
+    ffor<4>([&](auto qc) {
+      constexpr int q = decltype(qc)::v;
+      const int f = 32 * ot + 8 * q + 4 * half;
+      float4 cv = c ? *reinterpret_cast<const float4*>(c + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 dv = d ? *reinterpret_cast<const float4*>(d + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+      acc[ot][4 * q + 0] = m * cv.x + dv.x;
+      acc[ot][4 * q + 1] = m * cv.y + dv.y;
+      acc[ot][4 * q + 2] = m * cv.z + dv.z;
+      acc[ot][4 * q + 3] = m * cv.w + dv.w;
+    });
+  });
+}
+
+template <int OT, int ACT>
+__device__ __forceinline__ void act_tiles(f32x16 (&a)[OT]) {
+  ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+    ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; a[ot][r] = act_f<ACT>(a[ot][r]); }); });
+}
+
+// One butterfly stage of the transpose-reduce: the pair (in[2j], in[2j+1]) is split between the two
+// lanes of an exchange pair -- the lane with bit STEP clear keeps the sum of in[2j], its partner
+// the sum of in[2j+1] -- so the number of live values halves while the number of lanes summed doubles.
+template <int N, int STEP>
+__device__ __forceinline__ void bfly_stage(const float (&in)[N], float (&out)[N / 2], bool bit) {
+  ffor<N / 2>([&](auto jc) {
+    constexpr int j = decltype(jc)::v;
+    const float keep = bit ? in[2 * j + 1] : in[2 * j];
+    const float send = bit ? in[2 * j] : in[2 * j + 1];
+    out[j] = keep + lane_xchg<STEP>(send);
+  });
+}
+
+// Masked column sums of this wave's 32 particles for all 32*HT features -> partial[wave][feature].
+// Transpose-reduce butterfly: 16*HT*(1/2+1/4+..) exchanges instead of 16*HT*5; afterwards lane l
+// holds the flat register indices idx = 32 j + (l & 31)  (idx = 16 t + r of tile t, register r).
+template <int HT>
+__device__ __forceinline__ void pool_partials(const f32x16 (&x)[HT], float m, float* partial, int wave, int lane) {
+  constexpr int N0 = 16 * HT;
+  const int half = lane >> 5;
+  float a0[N0];
+  ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+    ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; a0[16 * t + r] = x[t][r] * m; }); });
+  float a1[N0 / 2], a2[N0 / 4], a3[N0 / 8], a4[N0 / 16];
+  bfly_stage<N0, 0>(a0, a1, (lane & 1) != 0);
+  bfly_stage<N0 / 2, 1>(a1, a2, (lane & 2) != 0);
+  bfly_stage<N0 / 4, 2>(a2, a3, (lane & 4) != 0);
+  bfly_stage<N0 / 8, 3>(a3, a4, (lane & 8) != 0);
+  float* dst = partial + wave * 128;
+  if constexpr (HT == 1) {                         // one value left: plain sum over the last lane bit
+    const float v = a4[0] + lane_xchg<4>(a4[0]);
+    const int r = lane & 15;
+    if ((lane & 16) == 0) dst[(r & 3) + 8 * (r >> 2) + 4 * half] = v;
+  } else {
+    float a5[N0 / 32];
+    bfly_stage<N0 / 16, 4>(a4, a5, (lane & 16) != 0);
+    ffor<N0 / 32>([&](auto jc) {
+      constexpr int j = decltype(jc)::v;
+      const int idx = 32 * j + (lane & 31);
+      const int t = idx >> 4, r = idx & 15;
+      dst[32 * t + (r & 3) + 8 * (r >> 2) + 4 * half] = a5[j];
+    });
+  }
+}
+
+// element k of  pooled = [sum/cnt, 0.01*sum, tail]  (epic.py:100-107) straight from the 4 wave partials
+template <int H>
+struct PooledIn {
+  const float* partial;
+  const float* tail;
+  float cnt;
+  __device__ __forceinline__ float operator()(int k) const {
+    if (k >= 2 * H) return tail[k - 2 * H];
+    const int f = k >= H ? k - H : k;
+    const float s = (partial[f] + partial[128 + f]) + (partial[256 + f] + partial[384 + f]);
+    return k >= H ? s * 0.01f : s / cnt;
+  }
+};
+
+// time vector c = W_t temb of a layer: taken from the per-grid-point table when the caller
+// precomputed it (generation: t is the same for every jet), else a matvec into L.cvec.
+template <int ET, int O>
+__device__ __forceinline__ const float* time_vec(const float* ctab, int& ci, const float* WtT, Lds& L, int tid) {
+  if (ctab != nullptr) {
+    const float* c = ctab + (int64_t)ci * 128;
+    ++ci;
+    return c;
+  }
+  matvec<MMB_ACT_NONE, ET, O>(WtT, nullptr, L.temb, L.cvec, nullptr, tid);
+  return L.cvec;
+}
+
+
+// ------------------------------------------------------------------ model dimensions ----
+template <int ET_, int EC_, int ED_, int HB_, int GB_, int DC_, int V_>
+struct Dims {
+  static constexpr int ET = ET_, EC = EC_, ED = ED_, HB = HB_, GB = GB_, DC = DC_, V = V_;
+  static constexpr int HBT = HB / 32;          // tiles per branch
+  static constexpr int HFT = 2 * HBT;          // tiles of the fused encoder
+  static constexpr int GF = 2 * GB;
+};
+
+typedef Dims<32, 16, 16, 64, 16, 3, 8> DimsS3;       // configs/S3_multimodal.yaml
+typedef Dims<16, 8, 8, 32, 8, 3, 8> DimsMid;         // the mm_mid golden / small models
+
+}  // namespace mmb

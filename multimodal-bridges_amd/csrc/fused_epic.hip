@@ -24,20 +24,10 @@
 // (cat[h1,h2], read once per layer and by the heads) in LDS -- 64 KiB per jet, each lane reading back
 // only what it wrote (no barrier, conflict-free b128) -- and by folding the residual into the
 // accumulator's initial value.  One jet's matvec latency then hides under the other jet's MFMAs.
-#include "common.h"
-#include <utility>
+
+#include "fused_common.h"
 
 namespace mmb {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-template <int I> struct IF { static constexpr int v = I; };
-template <typename F, int... Is>
-__device__ __forceinline__ void ffor_impl(F&& f, std::integer_sequence<int, Is...>) { (f(IF<Is>{}), ...); }
-template <int N, typename F>
-__device__ __forceinline__ void ffor(F&& f) { ffor_impl(f, std::make_integer_sequence<int, N>{}); }
-
-constexpr int FE_THREADS = 256;
 
 // Developer-only phase timing (build with MMB_EXTRA_FLAGS=-DMMB_FE_PROF, benchmarks/prof_fused.py):
 // thread 0 of block 0 accumulates core-clock cycles per phase category.
@@ -56,327 +46,29 @@ __device__ unsigned long long fe_prof[16];
 #endif
 enum { PF_EMBED = 0, PF_POOL, PF_GLOB1, PF_GLOB2, PF_DVEC, PF_LOC1, PF_LOC2, PF_EPI, PF_OUT, PF_PROJ_MMA, PF_HEAD, PF_STEP, PF_N };
 
-// ------------------------------------------------------------------ small helpers ------
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-
-// sum over the 32 lanes that share (lane >> 5); every lane of the half ends up with the sum
-__device__ __forceinline__ float half_sum32(float v) {
-  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]  (xor 1)
-  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]  (xor 2)
-  v += dpp_mov<0x141>(v);    // row_half_mirror      (other quad of the 8)
-  v += dpp_mov<0x140>(v);    // row_mirror           (other 8 of the 16)
-  v += __shfl_xor(v, 16, 64);
-  return v;
-}
-
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float lrelu_f(float x) { return x > 0.0f ? x : 0.01f * x; }
-template <int ACT>
-__device__ __forceinline__ float act_f(float x) {
-  if constexpr (ACT == MMB_ACT_GELU) return gelu_f(x);
-  if constexpr (ACT == MMB_ACT_LRELU) return lrelu_f(x);
-  return x;
-}
-
-// per-layer descriptor: offsets (in floats) into the packed parameter buffer, -1 = absent
-struct LDesc {
-  int wx;   // MFMA part, packed [KT][4][OT][64][4]        (per-particle layers)
-  int wt;   // transposed [Kt][O]: time part (per-particle layers) or the whole W^T (per-jet layers)
-  int wg;   // transposed [G][O]: global-vector part
-  int b;    // bias [O] (padded to a multiple of 32 for per-particle layers)
-};
-
-struct alignas(16) Lds {
-  float temb[128];
-  float gcur[64], gskip[64], gnew[64], gcat[64];
-  float partial[4 * 128];
-  float gh[128];
-  float cvec[128], dvec[128];
-  float cw[32 * 4], cb[32];       // continuous embedding weight [Ec][Dc<=4], bias
-  float table[8 * 32];            // discrete embedding table [V<=8][Ed<=32]
-  float cnt;
-  int red[4];
-  float park[4][FE_THREADS];      // generation loop: x (3) and k of this lane's particle while a forward runs
-#ifdef MMB_FE_PROF
-  unsigned long long tlast;
-#endif
-};
-
-// exchange with the lane whose index differs in bit BIT
-template <int BIT>
-__device__ __forceinline__ float lane_xchg(float v) {
-  if constexpr (BIT == 0) return dpp_mov<0xB1>(v);            // quad_perm [1,0,3,2]
-  else if constexpr (BIT == 1) return dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
-  else if constexpr (BIT == 3) return dpp_mov<0x128>(v);      // row_ror:8 == xor 8 inside a row of 16
-  else if constexpr (BIT == 2)
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x101F));   // xor 4
-  else if constexpr (BIT == 4)
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // xor 16
-  else return __shfl_xor(v, 32, 64);
-}
-
-constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x / 2); }
-
-// Per-jet matvec  out[o] = act( sum_k WT[k*O+o] v(k) + bias[o] ) + add[o]  with ONE barrier.
-// The O outputs are split over the 4 waves (OW each); inside a wave lane = part*G + og: og picks VW
-// consecutive outputs (one dwordx4/x2 per k), part picks every PARTS-th k.  The PARTS partial sums
-// live in lanes of the SAME wave and are folded with lane exchanges (no LDS round trip, no barrier);
-// the only barrier publishes `out` to the other waves.  vfn(k) yields the input element (LDS).
-template <int K, int O>
-struct WaveMV {
-  static_assert((O & (O - 1)) == 0 && O >= 8 && O <= 256, "WaveMV: O must be a power of two in [8,256]");
-  static constexpr int OW = O / 4;                       // outputs per wave
-  static constexpr int VW = OW >= 4 ? 4 : OW;            // outputs per lane
-  static constexpr int G = OW / VW;                      // lane groups along the outputs
-  static constexpr int PARTS = 64 / G;                   // k-partitions inside the wave
-  static constexpr int ITER = (K + PARTS - 1) / PARTS;
-  static constexpr bool RAGGED = (K % PARTS) != 0;
-  typedef float vec __attribute__((ext_vector_type(VW)));
-
-  template <int ACT, typename VFn>
-  static __device__ __forceinline__ void run(const float* __restrict__ WT, const float* __restrict__ bias, VFn&& vfn,
-                                             float* out, const float* add, int tid) {
-    const int lane = tid & 63, wave = tid >> 6;
-    const int og = lane & (G - 1), part = lane / G;
-    const int o0 = wave * OW + og * VW;
-    const vec* wp = reinterpret_cast<const vec*>(WT + o0);
-    vec bv;
-    ffor<VW>([&](auto ec) { bv[decltype(ec)::v] = 0.0f; });
-    if (bias != nullptr && part == 0) bv = *reinterpret_cast<const vec*>(bias + o0);
-    vec acc;
-    ffor<VW>([&](auto ec) { acc[decltype(ec)::v] = 0.0f; });
-    constexpr int UN = 12;                               // loads in flight per lane
-    ffor<(ITER + UN - 1) / UN>([&](auto cc) {
-      constexpr int c0 = decltype(cc)::v * UN;
-      constexpr int n = (ITER - c0) < UN ? (ITER - c0) : UN;
-      vec w[n];
-      ffor<n>([&](auto ic) {
-        constexpr int it = c0 + decltype(ic)::v;
-        int kk = part + it * PARTS;
-        if constexpr (RAGGED && it == ITER - 1) kk = kk < K ? kk : K - 1;
-        w[decltype(ic)::v] = wp[kk * (O / VW)];
-      });
-      ffor<n>([&](auto ic) {
-        constexpr int it = c0 + decltype(ic)::v;
-        const int kk = part + it * PARTS;
-        float vv;
-        if constexpr (RAGGED && it == ITER - 1) vv = kk < K ? vfn(kk) : 0.0f; else vv = vfn(kk);
-        acc += w[decltype(ic)::v] * vv;
-      });
-    });
-    // fold the PARTS partitions: lane bits log2(G) .. 5
-    ffor<6 - ilog2(G)>([&](auto bc) {
-      constexpr int bit = ilog2(G) + decltype(bc)::v;
-      ffor<VW>([&](auto ec) { constexpr int e = decltype(ec)::v; acc[e] += lane_xchg<bit>(acc[e]); });
-    });
-    if (part == 0) {
-      ffor<VW>([&](auto ec) {
-        constexpr int e = decltype(ec)::v;
-        float t = act_f<ACT>(acc[e] + bv[e]);
-        if (add) t += add[o0 + e];
-        out[o0 + e] = t;
-      });
-    }
-    __syncthreads();
-  }
-};
-
-template <int ACT, int K, int O>
-__device__ __forceinline__ void matvec(const float* __restrict__ WT, const float* __restrict__ bias, const float* v,
-                                       float* out, const float* add, int tid) {
-  WaveMV<K, O>::template run<ACT>(WT, bias, [&](int k) { return v[k]; }, out, add, tid);
-}
-
-// A lane's 16 values of tile t parked in / fetched from LDS: slot (t,q) holds one float4 per thread.
-__device__ __forceinline__ void park_tile(float4* S, int t, const f32x16& v, int tid) {
-  ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
-    S[(t * 4 + q) * FE_THREADS + tid] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]); });
-}
-__device__ __forceinline__ f32x16 fetch_tile(const float4* S, int t, int tid) {
-  f32x16 v;
-  ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
-    const float4 a = S[(t * 4 + q) * FE_THREADS + tid];
-    v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w; });
-  return v;
-}
-
-// Weight fragments are fetched with BUFFER loads: one descriptor for the packed parameter block
-// (SGPRs), the per-lane part of the address is the constant lane*16 in ONE VGPR, the fragment's
-// position is a wave-uniform SGPR offset -- no 64-bit per-load address arithmetic and no address
-// registers for the allocator to keep alive across the MFMA stream.
-typedef __amdgpu_buffer_rsrc_t WRsrc;
-__device__ __forceinline__ WRsrc weight_rsrc(const float* P) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, 0x7FFFFFFC, 0x00020000);
-}
-// float4 at packed float offset `woff` (uniform) + 64*f4 (uniform, float4 units) + this lane's float4
-__device__ __forceinline__ float4 wload(WRsrc R, int woff, int f4, int lane16) {
-  const auto v = __builtin_amdgcn_raw_buffer_load_b128(R, lane16, (woff + 4 * f4) * 4, 0);
-  static_assert(sizeof(v) == 16, "b128 buffer load");
-  return __builtin_bit_cast(float4, v);
-}
-
-// First A-operand group (k-steps 0..3 of every output tile) of a packed weight matrix, fetched
-// ahead of the GEMM that uses it -- while the previous GEMM or the per-jet chain runs -- so that no
-// GEMM starts with an exposed L2 round trip.
-template <int OT>
-struct AFrag {
-  float4 a[OT];
-};
-template <int OT>
-__device__ __forceinline__ void mma_prefetch(AFrag<OT>& f, WRsrc R, int woff, int lane) {
-  ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; f.a[ot] = wload(R, woff, ot * 64, lane * 16); });
-}
-
-// acc[ot] += W_x (tile rows ot) * X^T, X^T tiles delivered by `tile(IF<ft>)` (a reference to
-// registers, or a value fetched from LDS).  A-operand groups (4 k-steps x OT tiles, one dwordx4 per
-// lane and tile) run D groups ahead of the MFMAs through a ring of D+1 register buffers; D is
-// chosen so that the look-ahead is ~1000 MFMA cycles whatever OT is.
-template <int KT, int OT, typename TileFn>
-__device__ __forceinline__ void mma_x(f32x16 (&acc)[OT], TileFn&& tile, WRsrc R, int woff, int lane,
-                                      const AFrag<OT>& pre) {
-  constexpr int NG = KT * 4;
-  constexpr int D0 = OT >= 4 ? 1 : (OT == 2 ? 2 : 4);
-  constexpr int D = D0 < NG - 1 ? D0 : (NG - 1 > 0 ? NG - 1 : 1);
-  const int lane16 = lane * 16;
-  float4 ring[D + 1][OT];
-  ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; ring[0][ot] = pre.a[ot]; });
-  ffor<D - 1>([&](auto dc) {
-    constexpr int g = 1 + decltype(dc)::v;
-    if constexpr (g < NG)
-      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; ring[g][ot] = wload(R, woff, (g * OT + ot) * 64, lane16); });
-  });
-  ffor<KT>([&](auto fc) {
-    constexpr int ft = decltype(fc)::v;
-    decltype(auto) xt = tile(IF<ft>{});
-    ffor<4>([&](auto qc) {
-      constexpr int q = decltype(qc)::v;          // group = (ft, q): four k-steps r = 4q..4q+3
-      constexpr int g = ft * 4 + q;
-      constexpr int cur = g % (D + 1);
-      if constexpr (g + D < NG)
-        ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-          ring[(g + D) % (D + 1)][ot] = wload(R, woff, ((g + D) * OT + ot) * 64, lane16); });
-      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[cur][ot].x, xt[4 * q + 0], acc[ot], 0, 0, 0); });
-      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[cur][ot].y, xt[4 * q + 1], acc[ot], 0, 0, 0); });
-      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[cur][ot].z, xt[4 * q + 2], acc[ot], 0, 0, 0); });
-      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[cur][ot].w, xt[4 * q + 3], acc[ot], 0, 0, 0); });
-    });
-  });
-}
-
-// acc[ot][r] = m * c[f] + d[f]  (c, d in LDS or global; either may be null)
-template <int OT>
-__device__ __forceinline__ void acc_init(f32x16 (&acc)[OT], float m, const float* c, const float* d, int half) {
-  ffor<OT>([&](auto oc) {
-    constexpr int ot = decltype(oc)::v;
-    ffor<4>([&](auto qc) {
-      constexpr int q = decltype(qc)::v;
-      const int f = 32 * ot + 8 * q + 4 * half;
-      float4 cv = c ? *reinterpret_cast<const float4*>(c + f) : make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 dv = d ? *reinterpret_cast<const float4*>(d + f) : make_float4(0.f, 0.f, 0.f, 0.f);
-      acc[ot][4 * q + 0] = m * cv.x + dv.x;
-      acc[ot][4 * q + 1] = m * cv.y + dv.y;
-      acc[ot][4 * q + 2] = m * cv.z + dv.z;
-      acc[ot][4 * q + 3] = m * cv.w + dv.w;
-    });
-  });
-}
-
-template <int OT, int ACT>
-__device__ __forceinline__ void act_tiles(f32x16 (&a)[OT]) {
-  ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-    ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; a[ot][r] = act_f<ACT>(a[ot][r]); }); });
-}
-
-// One butterfly stage of the transpose-reduce: the pair (in[2j], in[2j+1]) is split between the two
-// lanes of an exchange pair -- the lane with bit STEP clear keeps the sum of in[2j], its partner
-// the sum of in[2j+1] -- so the number of live values halves while the number of lanes summed doubles.
-template <int N, int STEP>
-__device__ __forceinline__ void bfly_stage(const float (&in)[N], float (&out)[N / 2], bool bit) {
-  ffor<N / 2>([&](auto jc) {
-    constexpr int j = decltype(jc)::v;
-    const float keep = bit ? in[2 * j + 1] : in[2 * j];
-    const float send = bit ? in[2 * j] : in[2 * j + 1];
-    out[j] = keep + lane_xchg<STEP>(send);
-  });
-}
-
-// Masked column sums of this wave's 32 particles for all 32*HT features -> partial[wave][feature].
-// Transpose-reduce butterfly: 16*HT*(1/2+1/4+..) exchanges instead of 16*HT*5; afterwards lane l
-// holds the flat register indices idx = 32 j + (l & 31)  (idx = 16 t + r of tile t, register r).
-template <int HT>
-__device__ __forceinline__ void pool_partials(const f32x16 (&x)[HT], float m, float* partial, int wave, int lane) {
-  constexpr int N0 = 16 * HT;
-  const int half = lane >> 5;
-  float a0[N0];
-  ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
-    ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; a0[16 * t + r] = x[t][r] * m; }); });
-  float a1[N0 / 2], a2[N0 / 4], a3[N0 / 8], a4[N0 / 16];
-  bfly_stage<N0, 0>(a0, a1, (lane & 1) != 0);
-  bfly_stage<N0 / 2, 1>(a1, a2, (lane & 2) != 0);
-  bfly_stage<N0 / 4, 2>(a2, a3, (lane & 4) != 0);
-  bfly_stage<N0 / 8, 3>(a3, a4, (lane & 8) != 0);
-  float* dst = partial + wave * 128;
-  if constexpr (HT == 1) {                         // one value left: plain sum over the last lane bit
-    const float v = a4[0] + lane_xchg<4>(a4[0]);
-    const int r = lane & 15;
-    if ((lane & 16) == 0) dst[(r & 3) + 8 * (r >> 2) + 4 * half] = v;
-  } else {
-    float a5[N0 / 32];
-    bfly_stage<N0 / 16, 4>(a4, a5, (lane & 16) != 0);
-    ffor<N0 / 32>([&](auto jc) {
-      constexpr int j = decltype(jc)::v;
-      const int idx = 32 * j + (lane & 31);
-      const int t = idx >> 4, r = idx & 15;
-      dst[32 * t + (r & 3) + 8 * (r >> 2) + 4 * half] = a5[j];
-    });
-  }
-}
-
-// element k of  pooled = [sum/cnt, 0.01*sum, tail]  (epic.py:100-107) straight from the 4 wave partials
-template <int H>
-struct PooledIn {
-  const float* partial;
-  const float* tail;
-  float cnt;
-  __device__ __forceinline__ float operator()(int k) const {
-    if (k >= 2 * H) return tail[k - 2 * H];
-    const int f = k >= H ? k - H : k;
-    const float s = (partial[f] + partial[128 + f]) + (partial[256 + f] + partial[384 + f]);
-    return k >= H ? s * 0.01f : s / cnt;
-  }
-};
-
-// time vector c = W_t temb of a layer: taken from the per-grid-point table when the caller
-// precomputed it (generation: t is the same for every jet), else a matvec into L.cvec.
-template <int ET, int O>
-__device__ __forceinline__ const float* time_vec(const float* ctab, int& ci, const float* WtT, Lds& L, int tid) {
-  if (ctab != nullptr) {
-    const float* c = ctab + (int64_t)ci * 128;
-    ++ci;
-    return c;
-  }
-  matvec<MMB_ACT_NONE, ET, O>(WtT, nullptr, L.temb, L.cvec, nullptr, tid);
-  return L.cvec;
-}
-
 // ------------------------------------------------------------------ one EPiC encoder ----
 // x: HT tiles (in/out), skip: HT tiles.  Global vector in L.gcur.  `li` walks the descriptors.
 template <int HT, int ET, int G>
 struct Epic {
   static constexpr int H = 32 * HT;
 
+  // pooled = [mean, 0.01*sum] of the wave partials (without the tail) -> the tape's (B, 2H) tensor
+  template <class TR>
+  static __device__ __forceinline__ void save_pooled(TR& tr, Lds& L, int tid) {
+    if constexpr (TR::on) {
+      float* dst = tr.row(2 * H);
+      const PooledIn<H> pin{L.partial, nullptr, L.cnt};
+      if (dst != nullptr)
+        for (int k = tid; k < 2 * H; k += FE_THREADS) dst[k] = pin(k);
+    }
+  }
+
   // EPiCLayer (epic.py:187-208) + the encoder-level skip add (:89-90).  skipf(IF<t>) yields skip tile t.
-  template <typename SkipFn>
+  // Training slots: pooled, gh, g_new, g_out, lh, l_out.
+  template <typename SkipFn, class TR>
   static __device__ __forceinline__ void layer(f32x16 (&x)[HT], SkipFn&& skipf, bool use_skip,
                                                const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
-                                               float m, int tid, const float* ctab, int& ci) {
+                                               float m, int tid, const float* ctab, int& ci, TR& tr) {
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const WRsrc R = weight_rsrc(P);
     const LDesc g1 = D[li], g2 = D[li + 1], l1 = D[li + 2], l2 = D[li + 3];
@@ -387,21 +79,44 @@ struct Epic {
     if constexpr (HT <= 2) mma_prefetch(pre1, R, l1.wx, lane);   // arrives under the per-jet chain
     __syncthreads();
     FE_PROF(L, PF_POOL);
+    save_pooled(tr, L, tid);
     WaveMV<2 * H + G, H>::template run<MMB_ACT_LRELU>(P + g1.wt, P + g1.b, PooledIn<H>{L.partial, L.gcur, L.cnt}, L.gh,
                                                       nullptr, tid);
+    if constexpr (TR::on) tr.vec(L.gh, H, tid);
     FE_PROF(L, PF_GLOB1);
     matvec<MMB_ACT_NONE, H, G>(P + g2.wt, P + g2.b, L.gh, L.gnew, L.gcur, tid);      // g' = g + fc_glob2(.)
+    if constexpr (TR::on) tr.vec(L.gnew, G, tid);
     FE_PROF(L, PF_GLOB2);
     const float* cv = time_vec<ET, H>(ctab, ci, P + l1.wt, L, tid);
     matvec<MMB_ACT_NONE, G, H>(P + l1.wg, P + l1.b, L.gnew, L.dvec, nullptr, tid);
     FE_PROF(L, PF_DVEC);
-    if (tid < G) L.gcur[tid] = lrelu_f(L.gnew[tid]) + (use_skip ? L.gskip[tid] : 0.0f);
+    if constexpr (TR::on) {
+      const bool dr = tr.drop_p > 0.0f;
+      if (dr) ++tr.off;
+      const SaveSlot so = tr.next();
+      if (tid < G) {
+        float v = lrelu_f(L.gnew[tid]);
+        if (dr) {
+          const uint64_t idx = (uint64_t)tr.b * G + tid;
+          uint32_t r[4];
+          philox4(tr.seed, tr.off, idx >> 2, 0xD0D0u, r);
+          v = tr.drop(v, r[idx & 3]);
+        }
+        v += use_skip ? L.gskip[tid] : 0.0f;
+        L.gcur[tid] = v;
+        const int64_t i = (int64_t)tr.b * so.ld + tid;
+        if (i < so.n) so.p[i] = v;
+      }
+    } else {
+      if (tid < G) L.gcur[tid] = lrelu_f(L.gnew[tid]) + (use_skip ? L.gskip[tid] : 0.0f);
+    }
     f32x16 lh[HT];
     if constexpr (HT > 2) mma_prefetch(pre1, R, l1.wx, lane);    // (wide encoder: no registers to spare earlier)
     acc_init<HT>(lh, m, cv, L.dvec, half);
     if constexpr (HT <= 2) mma_prefetch(pre2, R, l2.wx, lane);   // arrives under the first GEMM
     mma_x<HT, HT>(lh, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, R, l1.wx, lane, pre1);
     act_tiles<HT, MMB_ACT_LRELU>(lh);
+    if constexpr (TR::on) tr.template tiles<HT>(lh, half);
     if constexpr (HT > 2) mma_prefetch(pre2, R, l2.wx, lane);
     FE_PROF(L, PF_LOC1);
     // x <- (x + b2) + W2 lh : the residual rides in the accumulator, x's registers ARE the accumulator
@@ -411,22 +126,37 @@ struct Epic {
         x[t][4 * q + 0] += bv.x; x[t][4 * q + 1] += bv.y; x[t][4 * q + 2] += bv.z; x[t][4 * q + 3] += bv.w; }); });
     mma_x<HT, HT>(x, [&](auto fc) -> const f32x16& { return lh[decltype(fc)::v]; }, R, l2.wx, lane, pre2);
     FE_PROF(L, PF_LOC2);
+    bool dr = false;
+    if constexpr (TR::on) {
+      dr = tr.drop_p > 0.0f;
+      if (dr) ++tr.off;
+    }
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+      ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; x[t][r] = lrelu_f(x[t][r]); });
+      if constexpr (TR::on) {
+        if (dr) {
+          ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
+            const uint64_t idx = ((uint64_t)tr.b * tr.N + tr.p) * H + (32 * t + 8 * q + 4 * half);
+            uint32_t rr[4];
+            philox4(tr.seed, tr.off, idx >> 2, 0xD0D0u, rr);
+            ffor<4>([&](auto ec) { constexpr int e = decltype(ec)::v; x[t][4 * q + e] = tr.drop(x[t][4 * q + e], rr[e]); }); });
+        }
+      }
       if (use_skip) {
         const f32x16 sk = skipf(IF<t>{});
-        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; x[t][r] = lrelu_f(x[t][r]) + sk[r]; });
-      } else {
-        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; x[t][r] = lrelu_f(x[t][r]); });
+        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; x[t][r] += sk[r]; });
       } });
+    if constexpr (TR::on) tr.template tiles<HT>(x, half);
     __syncthreads();                                   // gcur settled before the next pooled build
     FE_PROF(L, PF_EPI);
   }
 
   // output layer: wn Linear on cat[t, x, g] (epic.py:93-96); OTO output tiles, OW = true output width
-  template <int OTO, int OW>
+  // Training slot: out (only when OW is a whole number of tiles).
+  template <int OTO, int OW, class TR>
   static __device__ __forceinline__ void output(f32x16 (&out)[OTO], const f32x16 (&x)[HT],
                                                 const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
-                                                float m, int tid, const float* ctab, int& ci) {
+                                                float m, int tid, const float* ctab, int& ci, TR& tr) {
     const int lane = tid & 63, half = lane >> 5;
     const WRsrc R = weight_rsrc(P);
     const LDesc o = D[li];
@@ -437,14 +167,16 @@ struct Epic {
     matvec<MMB_ACT_NONE, G, OW>(P + o.wg, P + o.b, L.gcur, L.dvec, nullptr, tid);
     acc_init<OTO>(out, m, cv, L.dvec, half);
     mma_x<HT, OTO>(out, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, R, o.wx, lane, pre);
+    if constexpr (TR::on && OW == 32 * OTO) tr.template tiles<OTO>(out, half);
     FE_PROF(L, PF_OUT);
   }
 
   // EPiCProjection (epic.py:145-159) from KIN padded input tiles delivered by xin(IF<t>)
-  template <int KIN, typename InFn>
+  // Training slots: p0 pre, p0 out, p2 pre, p2 out, pooled, q0 pre, q0 out, q2 pre, q2 out.
+  template <int KIN, typename InFn, class TR>
   static __device__ __forceinline__ void project(f32x16 (&x)[HT], InFn&& xin,
                                                  const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
-                                                 float m, int tid, const float* ctab, int& ci) {
+                                                 float m, int tid, const float* ctab, int& ci, TR& tr) {
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const WRsrc R = weight_rsrc(P);
     const LDesc p0 = D[li], p2 = D[li + 1], q0 = D[li + 2], q2 = D[li + 3];
@@ -456,16 +188,26 @@ struct Epic {
     f32x16 h[HT];
     acc_init<HT>(h, m, cv, P + p0.b, half);
     mma_x<KIN, HT>(h, xin, R, p0.wx, lane, pre0);
+    if constexpr (TR::on) tr.template tiles<HT>(h, half);
     act_tiles<HT, MMB_ACT_GELU>(h);
+    if constexpr (TR::on) tr.template tiles<HT>(h, half);
     acc_init<HT>(x, 0.0f, nullptr, P + p2.b, half);
     mma_x<HT, HT>(x, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, R, p2.wx, lane, pre2);
+    if constexpr (TR::on) tr.template tiles<HT>(x, half);
     act_tiles<HT, MMB_ACT_GELU>(x);
+    if constexpr (TR::on) tr.template tiles<HT>(x, half);
     FE_PROF(L, PF_PROJ_MMA);
     pool_partials<HT>(x, m, L.partial, wave, lane);
     __syncthreads();                                   // context = time embedding (dim_context = Et)
+    save_pooled(tr, L, tid);
+    float* pre_q0 = nullptr;
+    if constexpr (TR::on) pre_q0 = tr.row(H);
     WaveMV<2 * H + ET, H>::template run<MMB_ACT_GELU>(P + q0.wt, P + q0.b, PooledIn<H>{L.partial, L.temb, L.cnt}, L.gh,
-                                                      nullptr, tid);
-    matvec<MMB_ACT_GELU, H, G>(P + q2.wt, P + q2.b, L.gh, L.gcur, nullptr, tid);
+                                                      nullptr, tid, pre_q0);
+    float* pre_q2 = nullptr;
+    if constexpr (TR::on) { tr.vec(L.gh, H, tid); pre_q2 = tr.row(G); }
+    matvec<MMB_ACT_GELU, H, G>(P + q2.wt, P + q2.b, L.gh, L.gcur, nullptr, tid, pre_q2);
+    if constexpr (TR::on) tr.vec(L.gcur, G, tid);
     FE_PROF(L, PF_GLOB1);
   }
 };
@@ -487,14 +229,6 @@ struct GenArgs {
   const float* delta_w;      // (steps,B,N,DC) injected Wiener increments or NULL -> Philox/Box-Muller
 };
 
-// ------------------------------------------------------------------ model dimensions ----
-template <int ET_, int EC_, int ED_, int HB_, int GB_, int DC_, int V_>
-struct Dims {
-  static constexpr int ET = ET_, EC = EC_, ED = ED_, HB = HB_, GB = GB_, DC = DC_, V = V_;
-  static constexpr int HBT = HB / 32;          // tiles per branch
-  static constexpr int HFT = 2 * HBT;          // tiles of the fused encoder
-  static constexpr int GF = 2 * GB;
-};
 
 struct FusedArgs {
   const float* ctab;       // generation: (n_c_layers,128) time vectors W_t temb of the CURRENT grid point, or NULL
@@ -529,9 +263,11 @@ __device__ __forceinline__ void embed_tiles(f32x16& tc, f32x16& td, const float 
 
 // Whole MultiModalEPiC forward for this jet.  which: 0 continuous head, 1 discrete head, 2 both.
 // hc: tile whose features 0..DC-1 are the drift; hd: tile whose features 0..V-1 are the logits.
-template <class DM>
+// Training (TR = Train): slots in execution order -- per branch [projection 9, layers 6 each, output 1],
+// the concatenated global vector 1, fused encoder [layers 6 each, output 1], heads [pre, hidden] x 2.
+template <class DM, class TR>
 __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* S, const float (&xp)[4], int kp, float m,
-                                            int which, f32x16& hc, f32x16& hd, int tid) {
+                                            int which, f32x16& hc, f32x16& hd, int tid, TR& tr) {
   constexpr int HBT = DM::HBT, HFT = DM::HFT;
   const int lane = tid & 63, half = lane >> 5;
   int li = 0, ci = 0;
@@ -545,27 +281,28 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
     constexpr int br = decltype(bc)::v;
     f32x16 x[HBT], sk[HBT], out[HBT];
     Epic<HBT, DM::ET, DM::GB>::template project<1>(x, [&](auto) -> const f32x16& { return br == 0 ? tc : td; }, A.P,
-                                                   A.D, li, L, m, tid, A.ctab, ci);
+                                                   A.D, li, L, m, tid, A.ctab, ci, tr);
     if (tid < DM::GB) L.gskip[tid] = L.gcur[tid];
     ffor<HBT>([&](auto t) { sk[decltype(t)::v] = x[decltype(t)::v]; });
     __syncthreads();
     for (int i = 0; i < A.nb_branch; ++i)
       Epic<HBT, DM::ET, DM::GB>::layer(x, [&](auto t) -> const f32x16& { return sk[decltype(t)::v]; },
-                                       A.use_skip != 0, A.P, A.D, li, L, m, tid, A.ctab, ci);
-    Epic<HBT, DM::ET, DM::GB>::template output<HBT, DM::HB>(out, x, A.P, A.D, li, L, m, tid, A.ctab, ci);
+                                       A.use_skip != 0, A.P, A.D, li, L, m, tid, A.ctab, ci, tr);
+    Epic<HBT, DM::ET, DM::GB>::template output<HBT, DM::HB>(out, x, A.P, A.D, li, L, m, tid, A.ctab, ci, tr);
     ffor<HBT>([&](auto t) { park_tile(S, br * HBT + decltype(t)::v, out[decltype(t)::v], tid); });
     if (tid < DM::GB) L.gcat[br * DM::GB + tid] = L.gcur[tid];
     __syncthreads();
   });
   // ---- fused encoder, no projection (K2: nb_fused_exec = constructed - 1)
   if (tid < DM::GF) { L.gcur[tid] = L.gcat[tid]; L.gskip[tid] = L.gcat[tid]; }
+  if constexpr (TR::on) tr.vec(L.gcat, DM::GF, tid);
   __syncthreads();
   f32x16 x[HFT], f[HFT];
   ffor<HFT>([&](auto t) { x[decltype(t)::v] = fetch_tile(S, decltype(t)::v, tid); });
   for (int i = 0; i < A.nb_fused_exec; ++i)
     Epic<HFT, DM::ET, DM::GF>::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, decltype(t)::v, tid); },
-                                     A.use_skip != 0, A.P, A.D, li, L, m, tid, A.ctab, ci);
-  Epic<HFT, DM::ET, DM::GF>::template output<HFT, 2 * DM::HB>(f, x, A.P, A.D, li, L, m, tid, A.ctab, ci);
+                                     A.use_skip != 0, A.P, A.D, li, L, m, tid, A.ctab, ci, tr);
+  Epic<HFT, DM::ET, DM::GF>::template output<HFT, 2 * DM::HB>(f, x, A.P, A.D, li, L, m, tid, A.ctab, ci, tr);
   // ---- heads (multimodal_epic.py:187-189): cat[t, f_i, h_i] -> GELU -> out
   const LDesc c0 = A.D[li], c2 = A.D[li + 1], d0 = A.D[li + 2], d2 = A.D[li + 3];
   const WRsrc R = weight_rsrc(A.P);
@@ -583,7 +320,9 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
     mma_x<HFT, HBT>(h, [&](auto fc) -> f32x16 {
       constexpr int t = decltype(fc)::v;
       if constexpr (t < HBT) return f[t]; else return fetch_tile(S, t - HBT, tid); }, R, c0.wx, lane, pre0);
+    if constexpr (TR::on) tr.template tiles<HBT>(h, half);
     act_tiles<HBT, MMB_ACT_GELU>(h);
+    if constexpr (TR::on) tr.template tiles<HBT>(h, half);
     f32x16 o[1];
     acc_init<1>(o, 0.0f, nullptr, A.P + c2.b, half);
     mma_x<HBT, 1>(o, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, R, c2.wx, lane, pre2);
@@ -601,7 +340,9 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
     mma_x<HFT, HBT>(h, [&](auto fc) -> f32x16 {
       constexpr int t = decltype(fc)::v;
       if constexpr (t < HBT) return f[HBT + t]; else return fetch_tile(S, t, tid); }, R, d0.wx, lane, pre0);
+    if constexpr (TR::on) tr.template tiles<HBT>(h, half);
     act_tiles<HBT, MMB_ACT_GELU>(h);
+    if constexpr (TR::on) tr.template tiles<HBT>(h, half);
     f32x16 o[1];
     acc_init<1>(o, 0.0f, nullptr, A.P + d2.b, half);
     mma_x<HBT, 1>(o, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, R, d2.wx, lane, pre2);
@@ -663,7 +404,8 @@ fused_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64_t* __
     const int kp = valid ? (int)k[gp] : 0;
     __syncthreads();
     f32x16 hc, hd;
-    forward_jet<DM>(A, L, S, xp, kp, m, which, hc, hd, tid);
+    NoTrain nt;
+    forward_jet<DM>(A, L, S, xp, kp, m, which, hc, hd, tid, nt);
     if (valid && which != 1 && half == 0) {
 #pragma unroll
       for (int d = 0; d < DM::DC; ++d) head_c[gp * DM::DC + d] = hc[d];       // features 0..2 = regs 0..2, half 0
@@ -675,6 +417,46 @@ fused_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64_t* __
 #pragma unroll
         for (int v = 0; v < DM::V; ++v) head_d[gp * DM::V + v] = lg[v];
       }
+    }
+  }
+}
+
+// ---- training forward: both heads + every activation of the tape to HBM ---------------------
+template <class DM>
+__global__ void __launch_bounds__(FE_THREADS, 2)
+fused_train_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64_t* __restrict__ k,
+                           const float* __restrict__ temb, int64_t temb_stride, const SaveSlot* __restrict__ slots,
+                           int n_slots, float drop_p, uint64_t seed, uint64_t offset0, float* __restrict__ head_c,
+                           float* __restrict__ head_d) {
+  __shared__ Lds L;
+  __shared__ float4 S[DM::HFT * 4 * FE_THREADS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  load_constants<DM>(A, L, tid);
+  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+    __syncthreads();
+    if (tid < DM::ET) L.temb[tid] = temb[(int64_t)b * temb_stride + tid];
+    if (tid == 0) L.cnt = (float)A.counts[b];
+    const int p = 32 * wave + (lane & 31);
+    const bool valid = p < A.N;
+    const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
+    const float m = valid ? A.maskf[gp] : 0.0f;
+    float xp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < DM::DC; ++d) xp[d] = valid ? x[gp * DM::DC + d] : 0.0f;
+    const int kp = valid ? (int)k[gp] : 0;
+    __syncthreads();
+    Train tr{slots, n_slots, 0, b, A.N, p, drop_p, seed, offset0};
+    f32x16 hc, hd;
+    forward_jet<DM>(A, L, S, xp, kp, m, 2, hc, hd, tid, tr);
+    if (valid && half == 0) {
+#pragma unroll
+      for (int d = 0; d < DM::DC; ++d) head_c[gp * DM::DC + d] = hc[d];
+    }
+    float lg[DM::V];
+    gather_logits<DM>(hd, lg, lane);
+    if (valid && half == 0) {
+#pragma unroll
+      for (int v = 0; v < DM::V; ++v) head_d[gp * DM::V + v] = lg[v];
     }
   }
 }
@@ -779,7 +561,8 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
       };
       // Euler step on the drift head (solvers.py:21-25); padded slots move too (K3)
       park();
-      forward_jet<DM>(A, L, S, xp, kp, m, 0, hc, hd, tid);
+      NoTrain nt;
+      forward_jet<DM>(A, L, S, xp, kp, m, 0, hc, hd, tid, nt);
       unpark();
       {
         float v[3] = {hc[0], hc[1], hc[2]};
@@ -814,7 +597,7 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
       __syncthreads();
       // tau-leap on the logits head, which sees the UPDATED x at the same t (solvers.py:59-81)
       park();
-      forward_jet<DM>(A, L, S, xp, kp, m, 1, hc, hd, tid);
+      forward_jet<DM>(A, L, S, xp, kp, m, 1, hc, hd, tid, nt);
       unpark();
       float r[V];
       gather_logits<DM>(hd, r, lane);
@@ -847,6 +630,7 @@ __device__ __forceinline__ void forward_uni(const FusedArgs& A, Lds& L, float4* 
   constexpr int HT = DM::HT;
   const int lane = tid & 63, half = lane >> 5;
   int li = 0, ci = 0;
+  NoTrain nt;
   FE_PROF(L, PF_STEP);
   f32x16 td[DM::EDT];
   ffor<DM::EDT>([&](auto tc) { constexpr int t = decltype(tc)::v;
@@ -857,15 +641,15 @@ __device__ __forceinline__ void forward_uni(const FusedArgs& A, Lds& L, float4* 
   FE_PROF(L, PF_EMBED);
   f32x16 x[HT];
   Epic<HT, DM::ET, DM::G>::template project<DM::EDT>(x, [&](auto fc) -> const f32x16& { return td[decltype(fc)::v]; },
-                                                    A.P, A.D, li, L, m, tid, A.ctab, ci);
+                                                    A.P, A.D, li, L, m, tid, A.ctab, ci, nt);
   if (tid < DM::G) L.gskip[tid] = L.gcur[tid];
   ffor<HT>([&](auto t) { park_tile(S, decltype(t)::v, x[decltype(t)::v], tid); });
   __syncthreads();
   for (int i = 0; i < A.nb_branch; ++i)
     Epic<HT, DM::ET, DM::G>::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, decltype(t)::v, tid); },
-                                   A.use_skip != 0, A.P, A.D, li, L, m, tid, A.ctab, ci);
+                                   A.use_skip != 0, A.P, A.D, li, L, m, tid, A.ctab, ci, nt);
   f32x16 o[1];
-  Epic<HT, DM::ET, DM::G>::template output<1, DM::V>(o, x, A.P, A.D, li, L, m, tid, A.ctab, ci);
+  Epic<HT, DM::ET, DM::G>::template output<1, DM::V>(o, x, A.P, A.D, li, L, m, tid, A.ctab, ci, nt);
   hd = o[0];
 }
 
@@ -959,8 +743,6 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
 typedef UniDims<128, 128, 128, 16, 8> UniS2;         // configs/S2_discrete.yaml
 typedef UniDims<16, 16, 32, 8, 8> UniMid;            // the uni_mid golden
 
-typedef Dims<32, 16, 16, 64, 16, 3, 8> DimsS3;       // configs/S3_multimodal.yaml
-typedef Dims<16, 8, 8, 32, 8, 3, 8> DimsMid;         // the mm_mid golden / small models
 
 static int check_fused(const char* name, int B, int N, const void* P, const void* D, const void* maskf,
                        const void* counts) {
@@ -996,6 +778,33 @@ extern "C" int mmb_fused_epic_forward(int variant, int B, int N, const float* pa
     hipLaunchKernelGGL(fused_forward_kernel<DimsMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k, temb,
                        temb_stride, which, head_c, head_d);
   return check_launch("mmb_fused_epic_forward");
+}
+
+extern "C" int mmb_fused_epic_train_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
+                                            int nb_branch, int nb_fused_exec, int use_skip, int off_cw, int off_cb,
+                                            int off_table, const float* maskf, const int32_t* counts, const float* x,
+                                            const int64_t* k, const float* temb, int64_t temb_stride,
+                                            const void* slots, int n_slots, float drop_p, uint64_t seed,
+                                            uint64_t offset0, float* head_c, float* head_d, void* stream) {
+  int rc = check_fused("mmb_fused_epic_train_forward", B, N, packed, desc, maskf, counts);
+  if (rc) return rc;
+  MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_epic_train_forward: unknown variant %d", variant);
+  MMB_REQUIRE(x && k && temb && head_c && head_d && slots, "mmb_fused_epic_train_forward: NULL argument");
+  MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_fused_epic_train_forward: dropout p=%f outside [0,1)", drop_p);
+  const int expect = 2 * (10 + 6 * nb_branch) + 1 + 6 * nb_fused_exec + 1 + 4;
+  MMB_REQUIRE(n_slots == expect, "mmb_fused_epic_train_forward: %d save slots given, the architecture has %d", n_slots,
+              expect);
+  FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
+              off_table, B, N, maskf, counts};
+  const SaveSlot* tab = reinterpret_cast<const SaveSlot*>(slots);
+  const int grid = B < 4096 ? B : 4096;
+  if (variant == 0)
+    hipLaunchKernelGGL(fused_train_forward_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k,
+                       temb, temb_stride, tab, n_slots, drop_p, seed, offset0, head_c, head_d);
+  else
+    hipLaunchKernelGGL(fused_train_forward_kernel<DimsMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k,
+                       temb, temb_stride, tab, n_slots, drop_p, seed, offset0, head_c, head_d);
+  return check_launch("mmb_fused_epic_train_forward");
 }
 
 // variant: 0 = S2 widths (Et128 Ed128 H128 G16), 1 = Et16 Ed16 H32 G8

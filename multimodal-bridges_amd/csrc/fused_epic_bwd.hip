@@ -1,0 +1,419 @@
+// K-E fused, training backward: the reverse pass of the whole MultiModalEPiC for one jet inside one
+// workgroup.  Mirror of fused_epic.hip's forward_jet: gradients of activations stay TRANSPOSED in the
+// C/D layout of v_mfma_f32_32x32x2_f32 (lane&31 = particle), so dX^T = W^T dZ^T is the same MFMA stream
+// as the forward with the transposed weight pre-packed in fragment order, and nothing but the per-layer
+// dZ (row-major, what the weight-gradient kernel streams) and the per-jet column sums of dZ (the
+// gradients of the broadcast time / global-vector inputs) ever goes to HBM.  Saved activations come
+// back from the forward's slots with buffer loads (lanes of padded particles read 0).
+// Reference: autograd of encoders/multimodal_epic.py:158-194, encoders/epic.py:71-107,145-159,187-208.
+//
+// Rows of masked particles: the loss gradient is 0 there, every per-particle op is row-wise and the
+// pooling gradient is multiplied by the mask, so dZ is 0 on them in every layer -- masked and unmasked
+// column sums coincide and one butterfly per layer serves both the time and the global-vector segment.
+#include "fused_common.h"
+
+namespace mmb {
+
+// per layer, forward order: per-particle layers {Wx^T in fragment order, Wt (O,Et), Wg (O,G)},
+// per-jet layers {W[:, first segment] (O,K0), W[:, second segment] (O,K1), -}; -1 = absent
+struct BDesc {
+  int a, b, c;
+};
+
+struct alignas(16) LdsB {
+  float dtemb[128];                      // gradient of the time embedding, accumulated over the jet
+  float dg[64], dgskip[64], dgnew[64], dgcat[64];
+  float dgh[128], dzg[128];
+  float dpool[256];
+  float cpool[128];
+  float svec[128];
+  float partial[4 * 128];
+  float cnt;
+};
+
+struct BwdArgs {
+  const float* P;          // packed backward parameters
+  const BDesc* D;
+  int nb_branch, nb_fused_exec, use_skip;
+  int B, N;
+  const float* maskf;
+  const int32_t* counts;
+  const SaveSlot* slots;
+  int n_slots;
+  float drop_p;
+  uint64_t seed, offset0;
+};
+
+__device__ __forceinline__ float gelu_grad(float z) {
+  const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
+  return cdf + z * pdf;
+}
+__device__ __forceinline__ float lrelu_grad(float s) { return s > 0.0f ? 1.0f : 0.01f; }
+__device__ __forceinline__ float drop_grad(float g, uint32_t r, float p) { return u01(r) < p ? 0.0f : g / (1.0f - p); }
+
+template <int HT>
+__device__ __forceinline__ void zero_tiles(f32x16 (&x)[HT]) {
+  ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+    ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; x[t][r] = 0.0f; }); });
+}
+
+// acc += W^T-fragments * tiles
+template <int KT, int OT, typename TileFn>
+__device__ __forceinline__ void mma_go(f32x16 (&acc)[OT], TileFn&& tile, const float* P, int woff, int lane) {
+  const WRsrc R = weight_rsrc(P);
+  AFrag<OT> pre;
+  mma_prefetch(pre, R, woff, lane);
+  mma_x<KT, OT>(acc, tile, R, woff, lane, pre);
+}
+
+// s = column sums of the dZ tiles over the jet's particles -> LB.svec and row b of the next slot
+template <int HT>
+__device__ __forceinline__ void colsum(const f32x16 (&dz)[HT], LdsB& LB, Slots& sl, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  pool_partials<HT>(dz, 1.0f, LB.partial, wave, lane);
+  __syncthreads();
+  float* dst = sl.row(32 * HT);
+  if (tid < 32 * HT) {
+    const float s = (LB.partial[tid] + LB.partial[128 + tid]) + (LB.partial[256 + tid] + LB.partial[384 + tid]);
+    LB.svec[tid] = s;
+    if (dst != nullptr) dst[tid] = s;
+  }
+  __syncthreads();
+}
+
+// x[t][r] += m * c[feature]
+template <int HT>
+__device__ __forceinline__ void add_mc(f32x16 (&x)[HT], float m, const float* c, int half) {
+  ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+    ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
+      const float4 cv = *reinterpret_cast<const float4*>(c + 32 * t + 8 * q + 4 * half);
+      x[t][4 * q + 0] += m * cv.x; x[t][4 * q + 1] += m * cv.y; x[t][4 * q + 2] += m * cv.z; x[t][4 * q + 3] += m * cv.w; }); });
+}
+
+template <int HT, int ET, int G>
+struct EpicB {
+  static constexpr int H = 32 * HT;
+
+  // gradient of the masked mean/sum pooling (epic.py:100-107) added to dx; LB.dpool holds d pooled (2H)
+  static __device__ __forceinline__ void pool_bwd(f32x16 (&dx)[HT], LdsB& LB, float m, int tid, int half) {
+    if (tid < H) LB.cpool[tid] = LB.dpool[tid] / LB.cnt + 0.01f * LB.dpool[H + tid];
+    __syncthreads();
+    add_mc<HT>(dx, m, LB.cpool, half);
+  }
+
+  // output layer  out = W [m temb, x, g] + b.  Slots: S_out.  In: dout (its dZ, already in HBM).
+  // Out: dx = Wx^T dout, LB.dg = Wg^T s (+ add), LB.dtemb += Wt^T s.
+  template <int OTO>
+  static __device__ __forceinline__ void output_bwd(f32x16 (&dx)[HT], const f32x16 (&dout)[OTO], const BDesc o,
+                                                    const float* __restrict__ P, const float* add, LdsB& LB, Slots& sl,
+                                                    int tid) {
+    const int lane = tid & 63;
+    colsum<OTO>(dout, LB, sl, tid);
+    auto sv = [&](int k) { return LB.svec[k]; };
+    WaveMV<32 * OTO, ET>::template run<MMB_ACT_NONE>(P + o.b, nullptr, sv, LB.dtemb, LB.dtemb, tid);
+    WaveMV<32 * OTO, G>::template run<MMB_ACT_NONE>(P + o.c, nullptr, sv, LB.dg, add, tid);
+    zero_tiles<HT>(dx);
+    mma_go<OTO, HT>(dx, [&](auto fc) -> const f32x16& { return dout[decltype(fc)::v]; }, P, o.a, lane);
+  }
+
+  // EPiCLayer + encoder-level skip.  In: dx = d l_out, LB.dg = d g_out.  Out: dx = d x_local, LB.dg = d x_global;
+  // the skip gradients accumulate in S (tiles) and LB.dgskip.
+  // Slots: l_out, [skip], dz_l2, lh, dz_l1, S_l1, g_new, dz_g2, gh, dz_g1.
+  static __device__ __forceinline__ void layer_bwd(f32x16 (&dx)[HT], const BDesc* __restrict__ D, const float* __restrict__ P,
+                                                   bool use_skip, LdsB& LB, float4* S, Slots& sl, float m, int tid,
+                                                   float drop_p, uint64_t seed, uint64_t off_g, uint64_t off_l) {
+    const int lane = tid & 63, half = lane >> 5;
+    const BDesc g1 = D[0], g2 = D[1], l1 = D[2], l2 = D[3];
+    const bool dr = drop_p > 0.0f;
+    // ---- l_out = drop(lrelu(y1)) + skip ;  y1 = x + W2 lh + b2
+    const Rows r_out = sl.rows();
+    Rows r_skip = r_out;
+    if (use_skip) r_skip = sl.rows();
+    const Rows r_dz2 = sl.rows();
+    ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+      if (use_skip) {
+        f32x16 sk = fetch_tile(S, t, tid);
+        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; sk[r] += dx[t][r]; });
+        park_tile(S, t, sk, tid);
+      }
+      f32x16 a = load_tile(r_out, t);
+      if (use_skip) {
+        const f32x16 k = load_tile(r_skip, t);
+        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; a[r] -= k[r]; });
+      }
+      ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
+        uint32_t rr[4] = {0u, 0u, 0u, 0u};
+        if (dr) {
+          const uint64_t idx = ((uint64_t)sl.b * sl.N + sl.p) * H + (32 * t + 8 * q + 4 * half);
+          philox4(seed, off_l, idx >> 2, 0xD0D0u, rr);
+        }
+        ffor<4>([&](auto ec) { constexpr int e = decltype(ec)::v;
+          float g = dx[t][4 * q + e];
+          if (dr) g = drop_grad(g, rr[e], drop_p);
+          dx[t][4 * q + e] = g * lrelu_grad(a[4 * q + e]); }); });
+      store_tile(r_dz2, t, dx[t]); });
+    // ---- d lh = W2^T d y1 ; lh = lrelu(z1)
+    f32x16 dlh[HT];
+    zero_tiles<HT>(dlh);
+    mma_go<HT, HT>(dlh, [&](auto fc) -> const f32x16& { return dx[decltype(fc)::v]; }, P, l2.a, lane);
+    const Rows r_lh = sl.rows(), r_dz1 = sl.rows();
+    ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+      const f32x16 a = load_tile(r_lh, t);
+      ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; dlh[t][r] *= lrelu_grad(a[r]); });
+      store_tile(r_dz1, t, dlh[t]); });
+    colsum<HT>(dlh, LB, sl, tid);
+    // d x = d y1 (residual) + Wx1^T d z1
+    mma_go<HT, HT>(dx, [&](auto fc) -> const f32x16& { return dlh[decltype(fc)::v]; }, P, l1.a, lane);
+    auto sv = [&](int k) { return LB.svec[k]; };
+    WaveMV<H, ET>::template run<MMB_ACT_NONE>(P + l1.b, nullptr, sv, LB.dtemb, LB.dtemb, tid);
+    WaveMV<H, G>::template run<MMB_ACT_NONE>(P + l1.c, nullptr, sv, LB.dgnew, nullptr, tid);
+    // ---- g_out = drop(lrelu(g')) + gskip ;  g' = g + W gh + b
+    const float* gnew = sl.row(G);
+    float* dzg2 = sl.row(G);
+    if (tid < G) {
+      float g = LB.dg[tid];
+      if (use_skip) LB.dgskip[tid] += g;
+      if (dr) {
+        const uint64_t idx = (uint64_t)sl.b * G + tid;
+        uint32_t rr[4];
+        philox4(seed, off_g, idx >> 2, 0xD0D0u, rr);
+        g = drop_grad(g, rr[idx & 3], drop_p);
+      }
+      g = g * lrelu_grad(gnew ? gnew[tid] : 0.0f) + LB.dgnew[tid];
+      LB.dgnew[tid] = g;
+      LB.dg[tid] = g;                                    // residual: d g_in starts as d g'
+      if (dzg2) dzg2[tid] = g;
+    }
+    __syncthreads();
+    matvec<MMB_ACT_NONE, G, H>(P + g2.a, nullptr, LB.dgnew, LB.dgh, nullptr, tid);
+    const float* gh = sl.row(H);
+    float* dzg1 = sl.row(H);
+    if (tid < H) {
+      const float v = LB.dgh[tid] * lrelu_grad(gh ? gh[tid] : 0.0f);
+      LB.dzg[tid] = v;
+      if (dzg1) dzg1[tid] = v;
+    }
+    __syncthreads();
+    matvec<MMB_ACT_NONE, H, 2 * H>(P + g1.a, nullptr, LB.dzg, LB.dpool, nullptr, tid);
+    matvec<MMB_ACT_NONE, H, G>(P + g1.b, nullptr, LB.dzg, LB.dg, LB.dg, tid);
+    pool_bwd(dx, LB, m, tid, half);
+    __syncthreads();
+  }
+
+  // EPiCProjection.  In: dx = d x (without the skip share), LB.dg = d g.  Slots: pre_q2, dz_q2, pre_q0, dz_q0,
+  // pre_p2, dz_p2, pre_p0, dz_p0, S_p0, [d_in (EIN wide) when EIN > 0].
+  template <int EIN>
+  static __device__ __forceinline__ void project_bwd(f32x16 (&dx)[HT], const BDesc* __restrict__ D, const float* __restrict__ P,
+                                                     bool use_skip, LdsB& LB, float4* S, Slots& sl, float m, int tid) {
+    const int lane = tid & 63, half = lane >> 5;
+    const BDesc p0 = D[0], p2 = D[1], q0 = D[2], q2 = D[3];
+    if (use_skip) {                                      // the projection's outputs ARE the skip tensors
+      ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+        const f32x16 sk = fetch_tile(S, t, tid);
+        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; dx[t][r] += sk[r]; }); });
+    }
+    const float* pre_q2 = sl.row(G);
+    float* dz_q2 = sl.row(G);
+    if (tid < G) {
+      const float g = (LB.dg[tid] + (use_skip ? LB.dgskip[tid] : 0.0f)) * gelu_grad(pre_q2 ? pre_q2[tid] : 0.0f);
+      LB.dgnew[tid] = g;
+      if (dz_q2) dz_q2[tid] = g;
+    }
+    __syncthreads();
+    matvec<MMB_ACT_NONE, G, H>(P + q2.a, nullptr, LB.dgnew, LB.dgh, nullptr, tid);
+    const float* pre_q0 = sl.row(H);
+    float* dz_q0 = sl.row(H);
+    if (tid < H) {
+      const float v = LB.dgh[tid] * gelu_grad(pre_q0 ? pre_q0[tid] : 0.0f);
+      LB.dzg[tid] = v;
+      if (dz_q0) dz_q0[tid] = v;
+    }
+    __syncthreads();
+    matvec<MMB_ACT_NONE, H, 2 * H>(P + q0.a, nullptr, LB.dzg, LB.dpool, nullptr, tid);
+    matvec<MMB_ACT_NONE, H, ET>(P + q0.b, nullptr, LB.dzg, LB.dtemb, LB.dtemb, tid);    // context = time embedding
+    pool_bwd(dx, LB, m, tid, half);
+    // ---- local MLP: x = gelu(z2), z2 = W2 h + b ; h = gelu(z0), z0 = W0 [m temb, x_in] + b
+    const Rows r_pre2 = sl.rows(), r_dz2 = sl.rows();
+    ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+      const f32x16 a = load_tile(r_pre2, t);
+      ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; dx[t][r] *= gelu_grad(a[r]); });
+      store_tile(r_dz2, t, dx[t]); });
+    f32x16 dh[HT];
+    zero_tiles<HT>(dh);
+    mma_go<HT, HT>(dh, [&](auto fc) -> const f32x16& { return dx[decltype(fc)::v]; }, P, p2.a, lane);
+    const Rows r_pre0 = sl.rows(), r_dz0 = sl.rows();
+    ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+      const f32x16 a = load_tile(r_pre0, t);
+      ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; dh[t][r] *= gelu_grad(a[r]); });
+      store_tile(r_dz0, t, dh[t]); });
+    colsum<HT>(dh, LB, sl, tid);
+    auto sv = [&](int k) { return LB.svec[k]; };
+    WaveMV<H, ET>::template run<MMB_ACT_NONE>(P + p0.b, nullptr, sv, LB.dtemb, LB.dtemb, tid);
+    if constexpr (EIN > 0) {
+      f32x16 din[1];
+      zero_tiles<1>(din);
+      mma_go<HT, 1>(din, [&](auto fc) -> const f32x16& { return dh[decltype(fc)::v]; }, P, p0.a, lane);
+      const Rows r = sl.rows();                          // (rows, EIN): only the column groups below EIN exist
+      ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
+        if (8 * q + 4 * half < EIN) {
+          const float4 v = make_float4(din[0][4 * q], din[0][4 * q + 1], din[0][4 * q + 2], din[0][4 * q + 3]);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r.R, r.vo, 8 * q * 4, 0);
+        } });
+    }
+  }
+};
+
+// Slot table: [0] d f (rows, 2HB: dZ of the fused output layer), [1] d h from the heads (rows, 2HB), [2] d cat[h1,h2]
+// (rows, 2HB: dZ of the branch output layers), [3] d temb (B, ET); then in the order the kernel walks:
+// heads (continuous, discrete): d_head, pre, dz, S;  fused encoder: S_out, layers last..first;
+// branches (continuous, discrete): S_out, layers last..first, projection (+ d_in for the continuous one).
+template <class DM>
+__global__ void __launch_bounds__(FE_THREADS, 2)
+fused_train_backward_kernel(BwdArgs A) {
+  __shared__ LdsB LB;
+  __shared__ float4 S[DM::HFT * 4 * FE_THREADS];
+  constexpr int HBT = DM::HBT, HFT = DM::HFT, HB = DM::HB, GB = DM::GB, GF = DM::GF, ET = DM::ET;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int nb = A.nb_branch, nbf = A.nb_fused_exec;
+  const bool use_skip = A.use_skip != 0;
+  const int base_f = 2 * (5 + 4 * nb), base_h = base_f + 4 * nbf + 1;
+  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+    __syncthreads();
+    const int p = 32 * wave + (lane & 31);
+    const bool valid = p < A.N;
+    const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
+    const float m = valid ? A.maskf[gp] : 0.0f;
+    if (tid == 0) LB.cnt = (float)A.counts[b];
+    if (tid < 128) LB.dtemb[tid] = 0.0f;
+    __syncthreads();
+    Slots sl{A.slots, A.n_slots, 4, b, A.N, p, half};
+    const SaveSlot s_df = sl.at(0), s_dhb = sl.at(1), s_dboth = sl.at(2), s_dtemb = sl.at(3);
+    // ---- heads: o = W2 h + b, h = gelu(W0 [m temb, f_i, h_i] + b)
+    ffor<2>([&](auto hc) {
+      constexpr int hi = decltype(hc)::v;
+      const BDesc h0 = A.D[base_h + 2 * hi], h2 = A.D[base_h + 2 * hi + 1];
+      const SaveSlot sd = sl.next();
+      f32x16 dzo[1];
+      zero_tiles<1>(dzo);
+      if constexpr (hi == 0) {
+        if (valid && half == 0 && (gp + 1) * sd.ld <= sd.n) {
+#pragma unroll
+          for (int d = 0; d < DM::DC; ++d) dzo[0][d] = sd.p[gp * sd.ld + d];
+        }
+      } else {
+        static_assert(DM::V == 8, "fused path is instantiated for vocab_size 8");
+        if (valid && (gp + 1) * sd.ld <= sd.n) {
+          const float4 v = *reinterpret_cast<const float4*>(sd.p + gp * sd.ld + 4 * half);
+          dzo[0][0] = v.x; dzo[0][1] = v.y; dzo[0][2] = v.z; dzo[0][3] = v.w;
+        }
+      }
+      f32x16 dh[HBT];
+      zero_tiles<HBT>(dh);
+      mma_go<1, HBT>(dh, [&](auto) -> const f32x16& { return dzo[0]; }, A.P, h2.a, lane);
+      const Rows r_pre = sl.rows(), r_dz = sl.rows();
+      ffor<HBT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+        const f32x16 a = load_tile(r_pre, t);
+        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; dh[t][r] *= gelu_grad(a[r]); });
+        store_tile(r_dz, t, dh[t]); });
+      colsum<HBT>(dh, LB, sl, tid);
+      WaveMV<HB, ET>::template run<MMB_ACT_NONE>(A.P + h0.b, nullptr, [&](int k) { return LB.svec[k]; }, LB.dtemb,
+                                                 LB.dtemb, tid);
+      f32x16 din[HFT];
+      zero_tiles<HFT>(din);
+      mma_go<HBT, HFT>(din, [&](auto fc) -> const f32x16& { return dh[decltype(fc)::v]; }, A.P, h0.a, lane);
+      const Rows r_df = sl.rows_of(s_df, hi * HB), r_dhb = sl.rows_of(s_dhb, hi * HB);
+      ffor<HBT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+        store_tile(r_df, t, din[t]);
+        store_tile(r_dhb, t, din[HBT + t]); });
+    });
+    // ---- fused encoder (no projection; its input and skip tensor is cat[h1, h2])
+    {
+      f32x16 dx[HFT];
+      {
+        f32x16 dout[HFT];
+        const Rows r = sl.rows_of(s_df);
+        ffor<HFT>([&](auto tc) { constexpr int t = decltype(tc)::v; dout[t] = load_tile(r, t); });
+        EpicB<HFT, ET, GF>::template output_bwd<HFT>(dx, dout, A.D[base_f + 4 * nbf], A.P, nullptr, LB, sl, tid);
+      }
+      if (use_skip) {
+        f32x16 z;
+        ffor<16>([&](auto rc) { z[decltype(rc)::v] = 0.0f; });
+        ffor<HFT>([&](auto tc) { park_tile(S, decltype(tc)::v, z, tid); });
+      }
+      if (tid < GF) LB.dgskip[tid] = 0.0f;
+      __syncthreads();
+      for (int i = nbf - 1; i >= 0; --i) {
+        const uint64_t j = (uint64_t)(2 * nb + i);
+        EpicB<HFT, ET, GF>::layer_bwd(dx, A.D + base_f + 4 * i, A.P, use_skip, LB, S, sl, m, tid, A.drop_p, A.seed,
+                                      A.offset0 + 2 * j + 1, A.offset0 + 2 * j + 2);
+      }
+      const Rows r_dhb = sl.rows_of(s_dhb), r_db = sl.rows_of(s_dboth);
+      ffor<HFT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+        const f32x16 a = load_tile(r_dhb, t);
+        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; dx[t][r] += a[r]; });
+        if (use_skip) {
+          const f32x16 sk = fetch_tile(S, t, tid);
+          ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; dx[t][r] += sk[r]; });
+        }
+        store_tile(r_db, t, dx[t]); });
+      if (tid < GF) LB.dgcat[tid] = LB.dg[tid] + (use_skip ? LB.dgskip[tid] : 0.0f);
+      __syncthreads();
+    }
+    // ---- the two branch encoders
+    ffor<2>([&](auto bc) {
+      constexpr int br = decltype(bc)::v;
+      const int base_b = br * (5 + 4 * nb);
+      f32x16 dx[HBT];
+      {
+        f32x16 dout[HBT];
+        const Rows r = sl.rows_of(s_dboth, br * HB);
+        ffor<HBT>([&](auto tc) { constexpr int t = decltype(tc)::v; dout[t] = load_tile(r, t); });
+        EpicB<HBT, ET, GB>::template output_bwd<HBT>(dx, dout, A.D[base_b + 4 + 4 * nb], A.P, LB.dgcat + br * GB, LB, sl,
+                                                     tid);
+      }
+      if (use_skip) {
+        f32x16 z;
+        ffor<16>([&](auto rc) { z[decltype(rc)::v] = 0.0f; });
+        ffor<HBT>([&](auto tc) { park_tile(S, decltype(tc)::v, z, tid); });
+      }
+      if (tid < GB) LB.dgskip[tid] = 0.0f;
+      __syncthreads();
+      for (int i = nb - 1; i >= 0; --i) {
+        const uint64_t j = (uint64_t)(br * nb + i);
+        EpicB<HBT, ET, GB>::layer_bwd(dx, A.D + base_b + 4 + 4 * i, A.P, use_skip, LB, S, sl, m, tid, A.drop_p, A.seed,
+                                      A.offset0 + 2 * j + 1, A.offset0 + 2 * j + 2);
+      }
+      EpicB<HBT, ET, GB>::template project_bwd<(br == 0 ? DM::EC : 0)>(dx, A.D + base_b, A.P, use_skip, LB, S, sl, m, tid);
+      __syncthreads();
+    });
+    float* dt = sl.row_of(s_dtemb, ET);
+    if (tid < ET && dt != nullptr) dt[tid] = LB.dtemb[tid];
+  }
+}
+
+}  // namespace mmb
+
+using namespace mmb;
+
+extern "C" int mmb_fused_epic_train_backward(int variant, int B, int N, const float* packed_bwd, const int32_t* desc_bwd,
+                                             int nb_branch, int nb_fused_exec, int use_skip, const float* maskf,
+                                             const int32_t* counts, const void* slots, int n_slots, float drop_p,
+                                             uint64_t seed, uint64_t offset0, void* stream) {
+  MMB_REQUIRE(B > 0 && N > 0 && N <= 128, "mmb_fused_epic_train_backward: needs 0 < N <= 128 (got B=%d N=%d)", B, N);
+  MMB_REQUIRE(packed_bwd && desc_bwd && maskf && counts && slots, "mmb_fused_epic_train_backward: NULL argument");
+  MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_epic_train_backward: unknown variant %d", variant);
+  MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_fused_epic_train_backward: dropout p=%f outside [0,1)", drop_p);
+  const int per_layer = use_skip ? 10 : 9;
+  const int expect = 4 + 8 + (1 + nb_fused_exec * per_layer) + 2 * (1 + nb_branch * per_layer + 9) + 1;
+  MMB_REQUIRE(n_slots == expect, "mmb_fused_epic_train_backward: %d slots given, the architecture has %d", n_slots,
+              expect);
+  BwdArgs A{packed_bwd, reinterpret_cast<const BDesc*>(desc_bwd), nb_branch, nb_fused_exec, use_skip, B, N, maskf,
+            counts, reinterpret_cast<const SaveSlot*>(slots), n_slots, drop_p, seed, offset0};
+  const int grid = B < 4096 ? B : 4096;
+  if (variant == 0)
+    hipLaunchKernelGGL(fused_train_backward_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A);
+  else
+    hipLaunchKernelGGL(fused_train_backward_kernel<DimsMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A);
+  return check_launch("mmb_fused_epic_train_backward");
+}

@@ -131,6 +131,43 @@ def _direct(p, touched):
     return p.grad.view(-1)
 
 
+def param_grads(layer, segs, dZ, S, Sm, arena, touched):
+    """dW, db of one weight-normed Linear from its dZ (M,Nout) and, for the broadcast segments, the per-jet column
+    sums of dZ (S unmasked for SEG_JET, Sm masked for SEG_JET_MASK), then through the weight norm into
+    weight_v / weight_g / bias.  Returns the effective weight."""
+    M, Nout = dZ.shape
+    W, inv = layer.weight(want_inv=True)
+    R = GW_REPLICAS if M >= 16384 else 1                # same-address atomics serialise: spread them
+    Kall = W.shape[1]
+    dWr = arena.take((R, Nout * Kall))
+    dbr = arena.take((R, Nout))
+    dW = dWr[0].view(Nout, Kall)
+    db = dbr[0]
+    rep = dict(replicas=R, rep_stride=dWr.stride(0), db_stride=dbr.stride(0))
+    koff = 0
+    first = True
+    for t, kind in segs:                                # per-particle inputs stream; broadcast inputs go
+        Ks = t.shape[1]                                 # through the per-jet sums of dZ (M = B rows)
+        dWs = dW[:, koff:koff + Ks]
+        if kind == SEG_ROW:
+            ops.grad_weight_rows(t, dZ, dWs, db if first else None, **rep)
+            first = False
+        elif kind == SEG_JET:
+            ops.grad_weight_rows(t, S, dWs, None)
+        else:
+            ops.grad_weight_rows(t, Sm, dWs, None)
+        koff += Ks
+    roff, rlen = layer._row_tables(W.device)
+    prm = (layer.weight_v, layer.weight_g, layer.bias)
+    outs = tuple(_direct(q, touched) for q in prm)
+    res = ops.weight_norm_bwd_rep(roff, rlen, layer.weight_v.detach().reshape(-1),
+                                  layer.weight_g.detach().reshape(-1), inv, dWr, dbr, out=outs)
+    for q, o, r in zip(prm, outs, res):
+        if o is None:                                   # no pre-zeroed bucket (or a second use): accumulate
+            _acc_param(q, r)
+    return W
+
+
 def _linear_bwd(e, store, produced, mi, seed, arena, touched):
     _, layer, N, segs, act, res1, post, res2, pre, y1, y2, p, off = e
     gY1, gY2 = store.get(y1), store.get(y2)
@@ -147,42 +184,12 @@ def _linear_bwd(e, store, produced, mi, seed, arena, touched):
         else:
             store.add(res1, dZ)         # dZ is only READ below
     # ---- parameters
-    W, inv = layer.weight(want_inv=True)
-    R = GW_REPLICAS if M >= 16384 else 1                # same-address atomics serialise: spread them
-    Kall = W.shape[1]
-    dWr = arena.take((R, Nout * Kall))
-    dbr = arena.take((R, Nout))
-    dW = dWr[0].view(Nout, Kall)
-    db = dbr[0]
-    rep = dict(replicas=R, rep_stride=dWr.stride(0), db_stride=dbr.stride(0))
     maskf = mi.maskf
     B = mi.B
-    S = Sm = None
-    koff = 0
-    first = True
-    for t, kind in segs:                                # per-particle inputs stream; broadcast inputs go
-        Ks = t.shape[1]                                 # through the per-jet sums of dZ (M = B rows)
-        dWs = dW[:, koff:koff + Ks]
-        if kind == SEG_ROW:
-            ops.grad_weight_rows(t, dZ, dWs, db if first else None, **rep)
-            first = False
-        elif kind == SEG_JET:
-            if S is None:
-                S = ops.jet_sum(dZ, B, N)
-            ops.grad_weight_rows(t, S, dWs, None)
-        else:
-            if Sm is None:
-                Sm = ops.jet_sum(dZ, B, N, maskf=maskf)
-            ops.grad_weight_rows(t, Sm, dWs, None)
-        koff += Ks
-    roff, rlen = layer._row_tables(W.device)
-    prm = (layer.weight_v, layer.weight_g, layer.bias)
-    outs = tuple(_direct(q, touched) for q in prm)
-    res = ops.weight_norm_bwd_rep(roff, rlen, layer.weight_v.detach().reshape(-1),
-                                  layer.weight_g.detach().reshape(-1), inv, dWr, dbr, out=outs)
-    for q, o, r in zip(prm, outs, res):
-        if o is None:                                   # no pre-zeroed bucket (or a second use): accumulate
-            _acc_param(q, r)
+    kinds = {k for _, k in segs}
+    S = ops.jet_sum(dZ, B, N) if SEG_JET in kinds else None
+    Sm = ops.jet_sum(dZ, B, N, maskf=maskf) if SEG_JET_MASK in kinds else None
+    W = param_grads(layer, segs, dZ, S, Sm, arena, touched)
     # ---- inputs
     need = [GradStore._key(t) in produced for t, _ in segs]
     if not any(need):
@@ -198,14 +205,7 @@ def _linear_bwd(e, store, produced, mi, seed, arena, touched):
             if kind == SEG_ROW:
                 ops.linear_cat([(dZ, SEG_ROW)], Wseg, None, N, residual=res, out=gx)
             else:
-                if kind == SEG_JET:
-                    if S is None:
-                        S = ops.jet_sum(dZ, B, N)
-                    red = S
-                else:
-                    if Sm is None:
-                        Sm = ops.jet_sum(dZ, B, N, maskf=maskf)
-                    red = Sm
+                red = S if kind == SEG_JET else Sm
                 ops.linear_cat([(red, SEG_ROW)], Wseg, None, 1, residual=res, out=gx)
         koff += Ks
 
@@ -233,6 +233,17 @@ def _embed_bwd(e, store, mi):
 
 def run_backward(model, tape, heads, d_hc, d_hd, d_s=None, scale=None):
     """Fill .grad of every parameter that took part in the taped forward."""
+    plan = next((e[1] for e in tape if e[0] == "fused_plan"), None)
+    if plan is not None and getattr(model, "use_fused_backward", True):
+        from encoders import fused_train
+        if scale is not None:
+            d_hc, d_hd = d_hc * scale, d_hd * scale
+            d_s = None if d_s is None else d_s * scale
+        fused_train.backward(model, plan, d_hc, d_hd)
+        lw = getattr(model.loss_multimode, "loss_weights", None)
+        if d_s is not None and isinstance(lw, torch.nn.Parameter):
+            _acc_param(lw, d_s)
+        return
     store = GradStore()
     if scale is not None:
         d_hc = None if d_hc is None else d_hc * scale

@@ -1,0 +1,239 @@
+"""Training step of MultiModalEPiC through the fused per-jet kernels (csrc/fused_epic.hip,
+csrc/fused_epic_bwd.hip).
+
+forward():  ONE launch (mmb_fused_epic_train_forward) computes both heads and writes every activation the
+            reverse pass reads.  This module lays out the destinations ("slots", in the kernel's execution
+            order) and records the SAME tape the layered forward (encoders/epic.py, multimodal_epic.py)
+            would have produced, so the layered reverse pass (encoders/backward.py) still applies.
+backward(): ONE launch (mmb_fused_epic_train_backward) runs the reverse pass of the whole encoder with the
+            activation gradients in registers and leaves, per weight-normed Linear, its dZ and the per-jet
+            column sums of dZ; the weight-gradient / weight-norm kernels then turn those into parameter
+            gradients exactly as the layered reverse pass does.
+
+Reference: encoders/multimodal_epic.py:158-194, encoders/epic.py:71-107,145-159,187-208 and their autograd."""
+import torch
+
+from mmb_hip import fused as fused_epic
+from mmb_hip.ops import SEG_ROW, SEG_JET, SEG_JET_MASK
+from tensorclass import TensorMultiModal
+
+
+def _slot(t):
+    return (t.data_ptr(), t.stride(0), t.untyped_storage().nbytes() // 4 - t.storage_offset())
+
+
+class _Plan:
+    def __init__(self, B, N, dev, tape, drop_p, offset0):
+        self.B, self.N, self.M, self.dev, self.tape = B, N, B * N, dev, tape
+        self.slots = []
+        self.drop_p, self.offset0, self.off = drop_p, offset0, offset0
+        self.enc = []                # per encoder (continuous, discrete, fused): dict(proj, layers, out)
+        self.heads = []
+
+    def slot(self, t):
+        self.slots.append(_slot(t))
+        return t
+
+    def rows(self, width):                       # one row per particle
+        return self.slot(torch.empty(self.M, width, dtype=torch.float32, device=self.dev))
+
+    def jets(self, width):                       # one row per jet
+        return self.slot(torch.empty(self.B, width, dtype=torch.float32, device=self.dev))
+
+    def next_offset(self):
+        if self.drop_p > 0.0:
+            self.off += 1
+            return self.drop_p, self.off
+        return 0.0, 0
+
+    def linear(self, layer, n, segs, act=None, res1=None, post=None, res2=None, pre=None, y1=None, y2=None, p=0.0,
+               off=0):
+        self.tape.append(("linear", layer, n, segs, act, res1, post, res2, pre, y1, y2, p, off))
+        return {"layer": layer, "segs": segs, "pre": pre, "y1": y1, "y2": y2}
+
+
+def _encoder(pl, enc, tseg, x_local, x_global, out):
+    N = pl.N
+    rec = {"proj": None, "layers": [], "skip": None}
+    if hasattr(enc, "epic_proj"):
+        pr = enc.epic_proj
+        H, G = pr.mlp_local["0"].dim_out, pr.mlp_global["2"].dim_out
+        pre, h = pl.rows(H), pl.rows(H)
+        p0 = pl.linear(pr.mlp_local["0"], N, [tseg, (x_local, SEG_ROW)], act="gelu", pre=pre, y1=h)
+        pre, h2 = pl.rows(H), pl.rows(H)
+        p2 = pl.linear(pr.mlp_local["2"], N, [(h, SEG_ROW)], act="gelu", pre=pre, y1=h2)
+        pooled = pl.jets(2 * H)
+        pl.tape.append(("pool", h2, pooled))
+        pre, g = pl.jets(H), pl.jets(H)
+        q0 = pl.linear(pr.mlp_global["0"], 1, [(pooled, SEG_ROW), (x_global, SEG_ROW)], act="gelu", pre=pre, y1=g)
+        pre, g2 = pl.jets(G), pl.jets(G)
+        q2 = pl.linear(pr.mlp_global["2"], 1, [(g, SEG_ROW)], act="gelu", pre=pre, y1=g2)
+        rec["proj"] = {"p0": p0, "p2": p2, "q0": q0, "q2": q2}
+        x_local, x_global = h2, g2
+    skip_l = x_local if enc.use_skip_connection else None
+    skip_g = x_global if enc.use_skip_connection else None
+    rec["skip"] = skip_l
+    for i in range(enc.num_blocks):
+        ly = enc.epic_layers[i]
+        H, G = ly.fc_loc2.dim_out, ly.fc_glob2.dim_out
+        pooled = pl.jets(2 * x_local.shape[1])
+        pl.tape.append(("pool", x_local, pooled))
+        gh = pl.jets(ly.fc_glob1.dim_out)
+        g1 = pl.linear(ly.fc_glob1, 1, [(pooled, SEG_ROW), (x_global, SEG_ROW)], act="lrelu", y1=gh)
+        g_new, g_out = pl.jets(G), pl.jets(G)
+        p, off = pl.next_offset()
+        g2 = pl.linear(ly.fc_glob2, 1, [(gh, SEG_ROW)], res1=x_global, post="lrelu", res2=skip_g, y1=g_new, y2=g_out,
+                       p=p, off=off)
+        lh = pl.rows(ly.fc_loc1.dim_out)
+        l1 = pl.linear(ly.fc_loc1, N, [tseg, (x_local, SEG_ROW), (g_new, SEG_JET)], act="lrelu", y1=lh)
+        l_out = pl.rows(H)
+        p, off = pl.next_offset()
+        l2 = pl.linear(ly.fc_loc2, N, [(lh, SEG_ROW)], res1=x_local, post="lrelu", res2=skip_l, y2=l_out, p=p, off=off)
+        rec["layers"].append({"g1": g1, "g2": g2, "l1": l1, "l2": l2})
+        x_local, x_global = l_out, g_out
+    pl.slot(out)
+    rec["out"] = pl.linear(enc.output_layer, N, [tseg, (x_local, SEG_ROW), (x_global, SEG_JET)], y1=out)
+    pl.enc.append(rec)
+    return out, x_global
+
+
+def forward(model, pack, loc, x, k, tape, seed, offset0):
+    """-> heads.  loc: the LocalState of embedder.embed (its tape entry is already recorded); x, k: the
+    raw bridge state the kernel embeds itself."""
+    enc = model.encoder
+    mi = loc.mi
+    B, N = mi.B, mi.N
+    dev = x.device
+    drop_p = float(model.config.encoder.dropout or 0.0) if model.training else 0.0
+    pl = _Plan(B, N, dev, tape, drop_p, offset0)
+    H0, H1, H2, half = enc.dims
+    tseg = (loc.temb, SEG_JET_MASK)
+    both = torch.empty(pl.M, H0 + H1, dtype=torch.float32, device=dev)
+    h1, g1 = _encoder(pl, enc.continuous_encoder, tseg, loc.cont_rows, loc.temb, both[:, :H0])
+    h2, g2 = _encoder(pl, enc.discrete_encoder, tseg, loc.disc_rows, loc.temb, both[:, H0:])
+    g = pl.jets(g1.shape[1] + g2.shape[1])
+    tape.append(("cat", [g1, g2], g))
+    f = torch.empty(pl.M, H2, dtype=torch.float32, device=dev)
+    _encoder(pl, enc.fused_encoder, tseg, both, g, f)
+    split = (H2 + 1) // 2
+    f1, f2 = f[:, :split], f[:, split:]
+    heads = []
+    for head, fi, hi in ((enc.continuous_head, f1, h1), (enc.discrete_head, f2, h2)):
+        pre, h = pl.rows(head["0"].dim_out), pl.rows(head["0"].dim_out)
+        heads.append((head, [tseg, (fi, SEG_ROW), (hi, SEG_ROW)], pre, h))
+    table = torch.tensor(pl.slots, dtype=torch.int64).to(dev, non_blocking=True)
+    hc, hd = fused_epic.train_forward(pack, mi, x, k, loc.temb, table, len(pl.slots), drop_p, seed, offset0)
+    for (head, segs, pre, h), y in zip(heads, (hc, hd)):
+        r0 = pl.linear(head["0"], N, segs, act="gelu", pre=pre, y1=h)
+        r2 = pl.linear(head["2"], N, [(h, SEG_ROW)], y1=y)
+        pl.heads.append({"0": r0, "2": r2})
+    pl.pack, pl.mi, pl.loc, pl.seed = pack, mi, loc, seed
+    pl.both_width = H0 + H1
+    pl.keep = (table, both, f, g)
+    tape.append(("fused_plan", pl))
+    return TensorMultiModal(None, hc.view(B, N, -1), hd.view(B, N, -1), loc.mask)
+
+
+class _Grads:
+    """GradStore look-alike for _embed_bwd: gradients by tensor identity."""
+
+    def __init__(self):
+        self.by_id = {}
+
+    def put(self, t, g):
+        self.by_id[id(t)] = g
+
+    def get(self, t):
+        return None if t is None else self.by_id.get(id(t))
+
+
+def backward(model, pl, d_hc, d_hd):
+    """Parameter gradients of the fused training forward `pl` given the head gradients (B,N,3), (B,N,8)."""
+    from encoders import backward as bw
+    from mmb_hip import ops
+    B, N, M, dev = pl.B, pl.N, pl.M, pl.dev
+    pack, mi = pl.pack, pl.mi
+    slots = []
+    jobs = []                         # (record, dZ, S)
+
+    def rows(w):
+        t = torch.empty(M, w, dtype=torch.float32, device=dev)
+        slots.append(_slot(t))
+        return t
+
+    def jets(w):
+        t = torch.empty(B, w, dtype=torch.float32, device=dev)
+        slots.append(_slot(t))
+        return t
+
+    def use(t):
+        slots.append(_slot(t))
+        return t
+
+    W2 = pl.both_width
+    Et = pl.loc.temb.shape[1]
+    d_f, d_hb, d_both, d_temb = rows(W2), rows(W2), rows(W2), jets(Et)
+    d_heads = (d_hc.reshape(M, -1).contiguous(), d_hd.reshape(M, -1).contiguous())
+    for hr, dh in zip(pl.heads, d_heads):
+        use(dh)
+        use(hr["0"]["pre"])
+        Hh = hr["0"]["pre"].shape[1]
+        dz, S = rows(Hh), jets(Hh)
+        jobs.append((hr["2"], dh, None))
+        jobs.append((hr["0"], dz, S))
+
+    def layers_bwd(rec):
+        for lr in reversed(rec["layers"]):
+            l_out = lr["l2"]["y2"]
+            H = l_out.shape[1]
+            G = lr["g2"]["y1"].shape[1]
+            use(l_out)
+            if rec["skip"] is not None:
+                use(rec["skip"])
+            dz_l2 = rows(H)
+            use(lr["l1"]["y1"])
+            dz_l1, S_l1 = rows(H), jets(H)
+            use(lr["g2"]["y1"])
+            dz_g2 = jets(G)
+            use(lr["g1"]["y1"])
+            dz_g1 = jets(lr["g1"]["y1"].shape[1])
+            jobs.extend([(lr["l2"], dz_l2, None), (lr["l1"], dz_l1, S_l1), (lr["g2"], dz_g2, None),
+                         (lr["g1"], dz_g1, None)])
+
+    fe = pl.enc[2]
+    jobs.append((fe["out"], d_f, jets(W2)))
+    layers_bwd(fe)
+    d_cont = None
+    for br in (0, 1):
+        rec = pl.enc[br]
+        Hb = rec["out"]["y1"].shape[1]
+        jobs.append((rec["out"], d_both[:, br * Hb:(br + 1) * Hb], jets(Hb)))
+        layers_bwd(rec)
+        pr = rec["proj"]
+        G = pr["q2"]["pre"].shape[1]
+        use(pr["q2"]["pre"])
+        dz_q2 = jets(G)
+        use(pr["q0"]["pre"])
+        dz_q0 = jets(pr["q0"]["pre"].shape[1])
+        use(pr["p2"]["pre"])
+        dz_p2 = rows(Hb)
+        use(pr["p0"]["pre"])
+        dz_p0, S_p0 = rows(Hb), jets(Hb)
+        jobs.extend([(pr["q2"], dz_q2, None), (pr["q0"], dz_q0, None), (pr["p2"], dz_p2, None), (pr["p0"], dz_p0, S_p0)])
+        if br == 0:
+            d_cont = rows(pl.loc.cont_rows.shape[1])
+    table = torch.tensor(slots, dtype=torch.int64).to(dev, non_blocking=True)
+    pbwd = fused_epic.packed_bwd(pack, fused_epic.params_version(model))
+    fused_epic.train_backward(pack, pbwd, mi, table, len(slots), pl.drop_p, pl.seed, pl.offset0)
+    # ---- parameter gradients: dW = dZ^T X per segment (broadcast segments: column sums, M = B rows), weight norm
+    n_acc = sum(bw.GW_REPLICAS * (r["layer"].weight_v.numel() + r["layer"].weight_v.shape[0] + 8) for r, _, _ in jobs)
+    arena = bw.Arena(n_acc, dev)
+    touched = set()
+    for r, dZ, S in jobs:
+        bw.param_grads(r["layer"], r["segs"], dZ, S, S, arena, touched)
+    emb = next(e for e in pl.tape if e[0] == "embed")
+    gs = _Grads()
+    gs.put(emb[4], d_temb)
+    if emb[5] is not None:
+        gs.put(emb[5], d_cont)
+    bw._embed_bwd(emb, gs, mi)

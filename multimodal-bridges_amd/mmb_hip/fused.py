@@ -68,10 +68,57 @@ def eligible(model):
     return VARIANTS.get((e.dim_emb_time, e.dim_emb_continuous, e.dim_emb_discrete, H0, hg[0]))
 
 
+class _IdxLin:
+    """Stands in for a WNLinear while the gather map of the packed buffer is built (see _IndexSource)."""
+
+    def __init__(self, w, b):
+        self._w, self.bias = w, b
+
+    def weight(self):
+        return self._w
+
+
+class _RealSource:
+    index = False
+
+    def lin(self, l):
+        return l
+
+    def tensor(self, getter):
+        return getter()
+
+
+class _IndexSource:
+    """Feeds the packer tensors whose VALUES are 1 + their position in the flat concatenation of all
+    sources (0 = padding), so that the packed result is a gather map: training re-packs the changed
+    parameters with one torch.cat + one index_select instead of ~10 small launches per layer."""
+    index = True
+
+    def __init__(self, device):
+        self.n, self.getters, self.device = 0, [], device
+
+    def _idx(self, shape, getter):
+        numel = 1
+        for d in shape:
+            numel *= d
+        t = (torch.arange(numel, device=self.device, dtype=torch.float32) + float(self.n + 1)).view(shape)
+        self.n += numel
+        assert self.n < (1 << 24), "gather map indices must stay exact in fp32"
+        self.getters.append(getter)
+        return t
+
+    def lin(self, l):
+        return _IdxLin(self._idx((l.dim_out, l.dim_in), l.weight), self._idx((l.dim_out,), l.bias.detach))
+
+    def tensor(self, getter):
+        return self._idx(tuple(getter().shape), getter)
+
+
 class _Packer:
     def __init__(self, device):
         self.chunks, self.n, self.desc, self.device = [], 0, [], device
         self.time_parts = []          # W[:, :Et] of every layer that consumes the time embedding, kernel order
+        self.time_lins = []
         self.mfma_flops = []          # 2*K_pad*O_pad of every per-particle layer (what the MFMAs execute)
 
     def add(self, t):
@@ -113,6 +160,7 @@ class _Packer:
         wt = self.add(Wt.t()) if n_t else -1
         if n_t:
             self.time_parts.append(Wt)
+            self.time_lins.append((lin, n_t))
         packed_x = self.pack_x(W[:, n_t:n_t + n_x])
         self.mfma_flops.append(2 * packed_x.numel())
         wx = self.add(packed_x)
@@ -122,6 +170,21 @@ class _Packer:
     def jet_layer(self, lin):
         W = lin.weight()
         self.desc.append([-1, self.add(W.t()), -1, self.add(lin.bias.detach())])
+
+    # ---- backward pack (csrc/fused_epic_bwd.hip, BDesc): transposed x-part in fragment order, the time and
+    # global-vector column blocks row-major (O,Kseg) -- the [K][O] layout of the kernel's matvec for W^T v
+    def particle_layer_bwd(self, lin, n_t, n_x, n_g):
+        W = lin.weight()
+        a = self.add(self.pack_x(W[:, n_t:n_t + n_x].t()))
+        b = self.add(W[:, :n_t]) if n_t else -1
+        c = self.add(W[:, n_t + n_x:]) if n_g else -1
+        self.desc.append([a, b, c])
+
+    def jet_layer_bwd(self, lin, k0):
+        W = lin.weight()
+        a = self.add(W[:, :k0])
+        b = self.add(W[:, k0:]) if k0 < W.shape[1] else -1
+        self.desc.append([a, b, -1])
 
 
 def pack_uni(model, variant):
@@ -160,6 +223,92 @@ def pack_model(model):
     variant = eligible(model)
     if variant is None:
         return None
+    pack = _pack_multi(model, variant, _RealSource())
+    src = _IndexSource(pack["packed"].device)
+    imap = _pack_multi(model, variant, src)["packed"]
+    assert imap.numel() == pack["packed"].numel()
+    idx = imap.long() - 1
+    pack["gather"] = torch.where(idx < 0, torch.full_like(idx, src.n), idx)       # padding -> the trailing zero
+    pack["getters"] = src.getters
+    pack["zero"] = torch.zeros(1, dtype=torch.float32, device=imap.device)
+    # backward weights (training): same sources, so the same flat buffer feeds a second gather
+    srcb = _IndexSource(imap.device)
+    bmap, pack["desc_bwd"] = _pack_multi_bwd(model, srcb)
+    assert srcb.n == src.n - _tail_sources(model)
+    idx = bmap.long() - 1
+    pack["gather_bwd"] = torch.where(idx < 0, torch.full_like(idx, src.n), idx)
+    pack["packed_bwd"] = None                              # built on first training use
+    pack["bwd_version"] = None
+    return pack
+
+
+def _tail_sources(model):
+    """floats of the sources the forward pack appends after the layers (embedding parameters)"""
+    emb = model.embedder
+    return (emb.continuous_embedding.weight.numel() + emb.continuous_embedding.bias.numel()
+            + emb.discrete_embedding.weight_v.numel())
+
+
+def packed_bwd(pack, version):
+    """Backward parameter buffer for the current parameter version (one cat + one index_select)."""
+    if pack["bwd_version"] != version:
+        flat = torch.cat([g().reshape(-1) for g in pack["getters"]] + [pack["zero"]])
+        if pack["packed_bwd"] is None:
+            pack["packed_bwd"] = flat.index_select(0, pack["gather_bwd"])
+        else:
+            torch.index_select(flat, 0, pack["gather_bwd"], out=pack["packed_bwd"])
+        pack["bwd_version"] = version
+    return pack["packed_bwd"]
+
+
+def _pack_multi_bwd(model, src):
+    """Index map of the backward parameter buffer + its descriptors (layer order = the forward pack's)."""
+    cfg = model.config
+    enc = model.encoder
+    Et = cfg.encoder.dim_emb_time
+    H0, H1, H2, half = enc.dims
+    G0 = cfg.encoder.dim_hidden_glob[0]
+    dev = next(model.parameters()).device
+    pk = _Packer(dev)
+    L = src.lin
+    for branch, n_in in ((enc.continuous_encoder, cfg.encoder.dim_emb_continuous),
+                         (enc.discrete_encoder, cfg.encoder.dim_emb_discrete)):
+        pr = branch.epic_proj
+        pk.particle_layer_bwd(L(pr.mlp_local["0"]), Et, n_in, 0)
+        pk.particle_layer_bwd(L(pr.mlp_local["2"]), 0, H0, 0)
+        pk.jet_layer_bwd(L(pr.mlp_global["0"]), 2 * H0)
+        pk.jet_layer_bwd(L(pr.mlp_global["2"]), H0)
+        for i in range(branch.num_blocks):
+            ly = branch.epic_layers[i]
+            pk.jet_layer_bwd(L(ly.fc_glob1), 2 * H0)
+            pk.jet_layer_bwd(L(ly.fc_glob2), H0)
+            pk.particle_layer_bwd(L(ly.fc_loc1), Et, H0, G0)
+            pk.particle_layer_bwd(L(ly.fc_loc2), 0, H0, 0)
+        pk.particle_layer_bwd(L(branch.output_layer), Et, H0, G0)
+    fe = enc.fused_encoder
+    for i in range(fe.num_blocks):
+        ly = fe.epic_layers[i]
+        pk.jet_layer_bwd(L(ly.fc_glob1), 2 * H2)
+        pk.jet_layer_bwd(L(ly.fc_glob2), H2)
+        pk.particle_layer_bwd(L(ly.fc_loc1), Et, H2, 2 * G0)
+        pk.particle_layer_bwd(L(ly.fc_loc2), 0, H2, 0)
+    pk.particle_layer_bwd(L(fe.output_layer), Et, H2, 2 * G0)
+    for head in (enc.continuous_head, enc.discrete_head):
+        pk.particle_layer_bwd(L(head["0"]), Et, half + H0, 0)
+        pk.particle_layer_bwd(L(head["2"]), 0, H0, 0)
+    desc = torch.tensor(pk.desc, dtype=torch.int32, device=dev).reshape(-1)
+    return torch.cat(pk.chunks), desc
+
+
+def repack(pack):
+    """Refresh the packed parameter buffer after an optimizer step (same architecture, new values)."""
+    flat = torch.cat([g().reshape(-1) for g in pack["getters"]] + [pack["zero"]])
+    torch.index_select(flat, 0, pack["gather"], out=pack["packed"])
+    pack["time_parts"] = [l.weight()[:, :n_t] for l, n_t in pack["time_lins"]]
+    return pack
+
+
+def _pack_multi(model, variant, src):
     cfg = model.config
     enc, emb = model.encoder, model.embedder
     Et = cfg.encoder.dim_emb_time
@@ -167,37 +316,41 @@ def pack_model(model):
     G0 = cfg.encoder.dim_hidden_glob[0]
     dev = next(model.parameters()).device
     pk = _Packer(dev)
+
+    def L(lin):
+        return src.lin(lin)
+
     for branch, n_in in ((enc.continuous_encoder, cfg.encoder.dim_emb_continuous),
                          (enc.discrete_encoder, cfg.encoder.dim_emb_discrete)):
         pr = branch.epic_proj
-        pk.particle_layer(pr.mlp_local["0"], Et, n_in, 0)
-        pk.particle_layer(pr.mlp_local["2"], 0, H0, 0)
-        pk.jet_layer(pr.mlp_global["0"])
-        pk.jet_layer(pr.mlp_global["2"])
+        pk.particle_layer(L(pr.mlp_local["0"]), Et, n_in, 0)
+        pk.particle_layer(L(pr.mlp_local["2"]), 0, H0, 0)
+        pk.jet_layer(L(pr.mlp_global["0"]))
+        pk.jet_layer(L(pr.mlp_global["2"]))
         for i in range(branch.num_blocks):
             ly = branch.epic_layers[i]
-            pk.jet_layer(ly.fc_glob1)
-            pk.jet_layer(ly.fc_glob2)
-            pk.particle_layer(ly.fc_loc1, Et, H0, G0)
-            pk.particle_layer(ly.fc_loc2, 0, H0, 0)
-        pk.particle_layer(branch.output_layer, Et, H0, G0)
+            pk.jet_layer(L(ly.fc_glob1))
+            pk.jet_layer(L(ly.fc_glob2))
+            pk.particle_layer(L(ly.fc_loc1), Et, H0, G0)
+            pk.particle_layer(L(ly.fc_loc2), 0, H0, 0)
+        pk.particle_layer(L(branch.output_layer), Et, H0, G0)
     fe = enc.fused_encoder
     for i in range(fe.num_blocks):                        # executed layers only (K2)
         ly = fe.epic_layers[i]
-        pk.jet_layer(ly.fc_glob1)
-        pk.jet_layer(ly.fc_glob2)
-        pk.particle_layer(ly.fc_loc1, Et, H2, 2 * G0)
-        pk.particle_layer(ly.fc_loc2, 0, H2, 0)
-    pk.particle_layer(fe.output_layer, Et, H2, 2 * G0)
+        pk.jet_layer(L(ly.fc_glob1))
+        pk.jet_layer(L(ly.fc_glob2))
+        pk.particle_layer(L(ly.fc_loc1), Et, H2, 2 * G0)
+        pk.particle_layer(L(ly.fc_loc2), 0, H2, 0)
+    pk.particle_layer(L(fe.output_layer), Et, H2, 2 * G0)
     for head in (enc.continuous_head, enc.discrete_head):
-        pk.particle_layer(head["0"], Et, half + H0, 0)
-        pk.particle_layer(head["2"], 0, H0, 0)
-    off_cw = pk.add(emb.continuous_embedding.weight.detach())
-    off_cb = pk.add(emb.continuous_embedding.bias.detach())
-    off_table = pk.add(emb.discrete_embedding.table())
+        pk.particle_layer(L(head["0"]), Et, half + H0, 0)
+        pk.particle_layer(L(head["2"]), 0, H0, 0)
+    off_cw = pk.add(src.tensor(emb.continuous_embedding.weight.detach))
+    off_cb = pk.add(src.tensor(emb.continuous_embedding.bias.detach))
+    off_table = pk.add(src.tensor(emb.discrete_embedding.table))
     packed = torch.cat(pk.chunks)
     desc = torch.tensor(pk.desc, dtype=torch.int32, device=dev).reshape(-1)
-    return {"kind": "multi", "packed": packed, "desc": desc, "variant": variant, "nb_branch": enc.continuous_encoder.num_blocks,
+    return {"kind": "multi", "packed": packed, "time_lins": pk.time_lins, "desc": desc, "variant": variant, "nb_branch": enc.continuous_encoder.num_blocks,
             "nb_fused_exec": fe.num_blocks, "use_skip": int(bool(cfg.encoder.skip_connection)),
             "off_cw": off_cw, "off_cb": off_cb, "off_table": off_table, "time_parts": pk.time_parts,
             # a generation forward evaluates ONE head (the last four particle layers are head_c.0/.2, head_d.0/.2)
@@ -230,6 +383,28 @@ def forward(pack, mi, x, k, temb, which, temb_stride=None):
          pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"], pack["off_table"], f32(mi.maskf),
          i32(mi.counts), f32(x, "x"), i64(k, "k"), f32(temb, "temb"), stride, which, f32(hc), f32(hd), stream())
     return hc, hd
+
+
+def train_forward(pack, mi, x, k, temb, slots, n_slots, drop_p, seed, offset0):
+    """Training forward: both heads + every activation of the tape (encoders/fused_train.py) -> HBM.
+    slots: device int64 tensor (n_slots, 3) of (pointer, row pitch, floats available)."""
+    B, N = mi.B, mi.N
+    dev = x.device
+    hc = torch.empty(B * N, 3, dtype=torch.float32, device=dev)
+    hd = torch.empty(B * N, 8, dtype=torch.float32, device=dev)
+    call("mmb_fused_epic_train_forward", pack["variant"], B, N, f32(pack["packed"]), i32(pack["desc"]),
+         pack["nb_branch"], pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"], pack["off_table"],
+         f32(mi.maskf), i32(mi.counts), f32(x, "x"), i64(k, "k"), f32(temb, "temb"), temb.stride(0),
+         C.c_void_p(slots.data_ptr()), n_slots, _fl(drop_p), seed, offset0, f32(hc), f32(hd), stream())
+    return hc, hd
+
+
+def train_backward(pack, pbwd, mi, slots, n_slots, drop_p, seed, offset0):
+    """Reverse pass of the whole encoder for every jet in one launch (csrc/fused_epic_bwd.hip): fills the dZ / column-sum
+    slots the weight-gradient kernel consumes.  slots: device int64 (n_slots, 3)."""
+    call("mmb_fused_epic_train_backward", pack["variant"], mi.B, mi.N, f32(pbwd), i32(pack["desc_bwd"]), pack["nb_branch"],
+         pack["nb_fused_exec"], pack["use_skip"], f32(mi.maskf), i32(mi.counts), C.c_void_p(slots.data_ptr()), n_slots,
+         _fl(drop_p), seed, offset0, stream())
 
 
 def generate(pack, mi, x, k, times, temb_steps, dt, thermo_kind, gamma, delta_n=None, seed=0, offset=0, ctab=None,

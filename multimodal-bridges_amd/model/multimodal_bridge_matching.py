@@ -101,6 +101,8 @@ class MultiModalBridgeMatching(nn.Module):
         self._calls = 0
         self._tape = None
         self.use_fused = True          # per-jet fused kernels when the architecture is eligible
+        self.use_fused_training = True # ... also for the taped training forward
+        self.use_fused_backward = True # ... and for its reverse pass
         self._fused_cache = None
 
     # ------------------------------------------------------------------ plumbing
@@ -130,8 +132,14 @@ class MultiModalBridgeMatching(nn.Module):
         if not self.use_fused:
             return None
         ver = fused_epic.params_version(self)
-        if self._fused_cache is None or self._fused_cache[0] != ver:
+        if self._fused_cache is None:
             self._fused_cache = (ver, fused_epic.pack_model(self))
+        elif self._fused_cache[0] != ver:
+            old = self._fused_cache[1]
+            if old is not None and "gather" in old and old["packed"].device == self.device:
+                self._fused_cache = (ver, fused_epic.repack(old))          # same architecture, new values
+            else:
+                self._fused_cache = (ver, fused_epic.pack_model(self))
         return self._fused_cache[1]
 
     @staticmethod
@@ -178,6 +186,12 @@ class MultiModalBridgeMatching(nn.Module):
         loc = self.embedder.embed(time, state.continuous, state.discrete, state.mask, mi=mi, tape=self._tape)
         glob = TensorMultiModal(time=loc.temb)
         off = self._next_offset() if (self.training and self.config.encoder.dropout) else 0
+        if self._tape is not None and self.use_fused_training:
+            pack = self._fused_pack()
+            if pack is not None and pack["kind"] == "multi" and self._pack_serves(pack, state):
+                from encoders import fused_train                        # taped forward in ONE launch
+                return fused_train.forward(self, pack, loc, state.continuous.contiguous(),
+                                           state.discrete.contiguous(), self._tape, self.seed, off)
         return self.encoder(loc, glob, tape=self._tape, seed=self.seed, offset0=off)
 
     # ------------------------------------------------------------------ training

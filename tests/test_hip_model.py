@@ -309,3 +309,76 @@ def test_fused_uni_matches_layered(golden, name):
     ha = torch.bincount(a.discrete[1][m].flatten(), minlength=8).float()
     hb = torch.bincount(b.discrete[1][m].flatten(), minlength=8).float()
     assert (ha / ha.sum() - hb / hb.sum()).abs().max() < 0.03
+
+
+@pytest.mark.parametrize("name", ["mm_mid", "S3"])
+@pytest.mark.parametrize("drop", [0.0, 0.2])
+def test_fused_training_matches_layered(golden, name, drop):
+    """Training step through the fused per-jet kernels (ONE forward launch that saves the tape, ONE backward launch
+    that leaves every layer's dZ) against the layered taped forward + layered reverse pass: same Philox dropout
+    masks -> same activations, heads, loss and parameter gradients."""
+    from tensorclass import TensorMultiModal
+    g = golden(name)
+    model = build(g).train()
+    model.config.encoder.dropout = drop
+    t = g.t
+    c = lambda a: None if a is None else a.cuda()
+    res = {}
+    for mode in ("fused", "fused_forward", "layered"):
+        model.use_fused_training = mode != "layered"
+        model.use_fused_backward = mode == "fused"
+        model.manual_seed(11)
+        state = TensorMultiModal(c(t["time"]), c(t["xt"]), c(t["kt"]), c(t["mask"]))
+        model._tape = []
+        heads = model.forward(state, None)
+        tape, model._tape = model._tape, None
+        model.manual_seed(11)
+        out = model.step_from_state(state, batch_of(g), "train", True)
+        model.zero_grad(set_to_none=True)
+        out["loss"].backward()
+        res[mode] = (heads, out["loss"].detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()
+                                                            if p.grad is not None}, tape)
+    hl, ll, gl, tl = res["layered"]
+    lin_l = [e for e in tl if e[0] == "linear"]
+    for mode in ("fused", "fused_forward"):
+        hf, lf, gf, tf = res[mode]
+        assert any(e[0] == "fused_plan" for e in tf), "the fused training forward did not run"
+        lin_f = [e for e in tf if e[0] == "linear"]
+        assert len(lin_f) == len(lin_l)
+        for ef, el in zip(lin_f, lin_l):               # every activation of the tape (same order in both tapes)
+            assert ef[1] is el[1] and ef[4] == el[4] and ef[6] == el[6] and ef[11] == el[11] and ef[12] == el[12]
+            for i in (8, 9, 10):
+                assert (ef[i] is None) == (el[i] is None), (ef[1], i)
+                if ef[i] is not None:
+                    close(ef[i], el[i], rtol=1e-4, atol=2e-5)
+        close(hf.continuous, hl.continuous, rtol=1e-4, atol=2e-5)
+        close(hf.discrete, hl.discrete, rtol=1e-4, atol=2e-5)
+        close(lf, ll, rtol=1e-5, atol=1e-6)
+        assert gf.keys() == gl.keys(), (mode, set(gf) ^ set(gl))
+        for n in gf:
+            scale = float(gl[n].abs().max()) + 1e-12
+            try:
+                close(gf[n], gl[n], rtol=2e-3, atol=2e-4 * scale + 1e-7)
+            except AssertionError as e:
+                raise AssertionError(f"{mode}: gradient of {n}: {e}") from None
+    if drop == 0.0:
+        close(res["fused"][0].discrete, t["head_discrete"], rtol=1e-4, atol=2e-5)
+
+
+def test_fused_repack_tracks_parameter_updates(golden):
+    """After an optimizer step the packed buffer is refreshed through the gather map (one cat + index_select);
+    it must equal a from-scratch packing."""
+    from mmb_hip import fused
+    g = golden("mm_mid")
+    model = build(g)
+    p0 = model._fused_pack()
+    assert "gather" in p0
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    p1 = model._fused_pack()
+    assert p1 is p0                                       # refreshed in place
+    fresh = fused.pack_model(model)
+    assert torch.equal(p1["packed"], fresh["packed"])
+    for a, b in zip(p1["time_parts"], fresh["time_parts"]):
+        assert torch.equal(a, b)

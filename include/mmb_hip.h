@@ -281,6 +281,21 @@ int mmb_grad_weight_rows(int M, const float* X, int64_t x_ld, int K, const float
                          int Nout, float* dW, int64_t dw_ld, float* db,
                          int replicas, int64_t rep_stride, int64_t db_stride, void* stream);
 
+/* ---- one launch for all layers of a model (a training step re-normalises ~60 small matrices and has ~100
+ * weight-gradient problems: launch-bound otherwise).  The tables live in device memory and hold 8-byte fields only
+ * (built on the host as int64 tensors).
+ * mmb_weight_norm_multi: one record per row {v row, g element | NULL = plain copy, destination row, 1/||v||
+ *   destination | NULL, length} -- torch.nn.utils.weight_norm as used in epic.py:4,67,132-141,180-183, embedder.py:61.
+ * mmb_weight_norm_bwd_multi: one record per row {v, g, inv, dW row (replica 0), db element (replica 0) | NULL,
+ *   dv out, dg out, db out | NULL, length, replicas, replica stride of dW, of db}; outputs are overwritten.
+ * mmb_grad_weight_rows_multi: records {X, dZ, dW, db | NULL, x_ld, dz_ld, dw_ld, rep_stride, db_stride, M, K, Nout,
+ *   rows per block, replicas, blocks along rows, blocks along K windows, first block id, end block id}, all of tile
+ *   class (OTb, KTb) = mmb_hip.ops.gw_class(K, Nout); semantics per record as mmb_grad_weight_rows (fast path only:
+ *   K, Nout, leading dimensions multiples of 4, 16-byte aligned operands). */
+int mmb_weight_norm_multi(int n_rows, const void* rows, void* stream);
+int mmb_weight_norm_bwd_multi(int n_rows, const void* rows, void* stream);
+int mmb_grad_weight_rows_multi(int OTb, int KTb, const void* probs, int n_probs, int total_blocks, void* stream);
+
 /* ---------------------------------------------------------------- K-E fused (generation) */
 /* Whole MultiModalEPiC forward (multimodal_epic.py:158-194 incl. embedder.py:74-80) for one jet
  * per workgroup with activations resident in registers; `packed`/`desc` come from

@@ -238,13 +238,13 @@ grad_weight_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restr
 // LDS and leave as one atomicAdd per element and block; db is the column sum of the A values.
 // Requires K and Nout to be multiples of 4 and 16-byte aligned rows (ragged last windows are zero-filled).
 template <int OT, int KT>
-__global__ void __launch_bounds__(256)
-grad_weight_rows_kernel(int M, const float* __restrict__ X, int64_t x_ld, int K, const float* __restrict__ dZ,
-                        int64_t dz_ld, int Nout, float* __restrict__ dW, int64_t dw_ld, float* __restrict__ db,
-                        int rows_per_block, int replicas, int64_t rep_stride, int64_t db_stride) {
+__device__ __forceinline__ void
+grad_weight_rows_body(int M, const float* __restrict__ X, int64_t x_ld, int K, const float* __restrict__ dZ,
+                      int64_t dz_ld, int Nout, float* __restrict__ dW, int64_t dw_ld, float* __restrict__ db,
+                      int rows_per_block, int replicas, int64_t rep_stride, int64_t db_stride, int bx, int by, int bz) {
   constexpr int R = 16;                                  // rows per chunk
   {                                                      // this block's replica of the accumulators
-    const int rep = blockIdx.x % replicas;
+    const int rep = bx % replicas;
     dW += rep * rep_stride;
     if (db != nullptr) db += rep * db_stride;
   }
@@ -256,8 +256,8 @@ grad_weight_rows_kernel(int M, const float* __restrict__ X, int64_t x_ld, int K,
   constexpr int LDSN = 4 * TILE > REDN ? 4 * TILE : REDN;
   __shared__ __attribute__((aligned(16))) float lds[LDSN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, i32 = lane & 31;
-  const int o0 = blockIdx.z * OW, k0 = blockIdx.y * KW;
-  const int r_begin = blockIdx.x * rows_per_block;
+  const int o0 = bz * OW, k0 = by * KW;
+  const int r_begin = bx * rows_per_block;
   const int r_end = min(M, r_begin + rows_per_block);
   float* xs = lds + wave * TILE;
   float* zs = xs + R * XP;
@@ -337,7 +337,7 @@ grad_weight_rows_kernel(int M, const float* __restrict__ X, int64_t x_ld, int K,
         if (o < Nout && col < K) atomicAdd(&dW[(int64_t)o * dw_ld + col], acc[ot][kt][e]); }); }); });
   }
   // db: one atomic per column and BLOCK (same-address atomics serialise at the memory side: ~60 ns each)
-  if (db != nullptr && blockIdx.y == 0) {
+  if (db != nullptr && by == 0) {
     sfor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
       float v = dbs[ot];
       v += __shfl_xor(v, 32, 64);
@@ -350,9 +350,68 @@ grad_weight_rows_kernel(int M, const float* __restrict__ X, int64_t x_ld, int K,
   }
 }
 
+template <int OT, int KT>
+__global__ void __launch_bounds__(256)
+grad_weight_rows_kernel(int M, const float* __restrict__ X, int64_t x_ld, int K, const float* __restrict__ dZ,
+                        int64_t dz_ld, int Nout, float* __restrict__ dW, int64_t dw_ld, float* __restrict__ db,
+                        int rows_per_block, int replicas, int64_t rep_stride, int64_t db_stride) {
+  grad_weight_rows_body<OT, KT>(M, X, x_ld, K, dZ, dz_ld, Nout, dW, dw_ld, db, rows_per_block, replicas, rep_stride,
+                                db_stride, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Many independent weight-gradient problems of one tile class in ONE launch (a training step has ~100 of
+// them, most far too small to fill the chip alone).  The device table holds one record per problem with its
+// range of linear block ids; a block finds its problem by a scalar scan.
+struct GwProb {            // all fields 8 bytes: built on the host as an int64 tensor
+  const float* X;
+  const float* dZ;
+  float* dW;
+  float* db;               // or NULL
+  int64_t x_ld, dz_ld, dw_ld, rep_stride, db_stride;
+  int64_t M, K, Nout, rpb, replicas;
+  int64_t nbx, nby;        // blocks along the rows / the K windows (the rest of the range: output windows)
+  int64_t block_begin, block_end;
+};
+
+template <int OT, int KT>
+__global__ void __launch_bounds__(256)
+grad_weight_rows_multi_kernel(const GwProb* __restrict__ probs, int n_probs) {
+  const int64_t id = blockIdx.x;
+  int i = 0;
+  while (i + 1 < n_probs && id >= probs[i].block_end) ++i;
+  const GwProb q = probs[i];
+  if (id < q.block_begin || id >= q.block_end) return;
+  const int local = (int)(id - q.block_begin);
+  const int bx = local % (int)q.nbx, rest = local / (int)q.nbx;
+  const int by = rest % (int)q.nby, bz = rest / (int)q.nby;
+  grad_weight_rows_body<OT, KT>((int)q.M, q.X, q.x_ld, (int)q.K, q.dZ, q.dz_ld, (int)q.Nout, q.dW, q.dw_ld, q.db,
+                                (int)q.rpb, (int)q.replicas, q.rep_stride, q.db_stride, bx, by, bz);
+}
+
 }  // namespace mmb
 
 using namespace mmb;
+
+// probs: device table of n_probs GwProb records of tile class (OTb, KTb) (see mmb_hip.ops.gw_class), ranges of
+// linear block ids ascending and contiguous from 0 to total_blocks.
+extern "C" int mmb_grad_weight_rows_multi(int OTb, int KTb, const void* probs, int n_probs, int total_blocks,
+                                          void* stream) {
+  MMB_REQUIRE(probs && n_probs > 0 && total_blocks > 0, "mmb_grad_weight_rows_multi: empty table");
+  const GwProb* P = reinterpret_cast<const GwProb*>(probs);
+  hipStream_t st = as_stream(stream);
+#define GWM(O_, K_) hipLaunchKernelGGL((grad_weight_rows_multi_kernel<O_, K_>), dim3(total_blocks), dim3(256), 0, st, P, n_probs)
+  if (OTb == 1 && KTb == 1) GWM(1, 1);
+  else if (OTb == 1 && KTb == 2) GWM(1, 2);
+  else if (OTb == 1 && KTb == 4) GWM(1, 4);
+  else if (OTb == 2 && KTb == 1) GWM(2, 1);
+  else if (OTb == 2 && KTb == 2) GWM(2, 2);
+  else if (OTb == 2 && KTb == 4) GWM(2, 4);
+  else if (OTb == 4 && KTb == 1) GWM(4, 1);
+  else if (OTb == 4 && KTb == 2) GWM(4, 2);
+  else MMB_REQUIRE(false, "mmb_grad_weight_rows_multi: no tile class (%d,%d)", OTb, KTb);
+#undef GWM
+  return check_launch("mmb_grad_weight_rows_multi");
+}
 
 extern "C" int mmb_grad_weight_rows(int M, const float* X, int64_t x_ld, int K, const float* dZ, int64_t dz_ld,
                                     int Nout, float* dW, int64_t dw_ld, float* db, int replicas, int64_t rep_stride,

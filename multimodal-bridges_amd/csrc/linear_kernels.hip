@@ -359,6 +359,73 @@ weight_norm_bwd_kernel(int n_rows, const int32_t* __restrict__ row_off, const in
   }
 }
 
+// ---- all layers of a model in ONE launch: a device table with one record per weight row ----------
+// (training re-normalises ~60 small matrices per step; 60 launches of a few hundred waves each are
+// launch-bound on the host AND on the GPU)
+struct WnRow {            // all fields 8 bytes: the table is built on the host as an int64 tensor
+  const float* v;         // source row
+  const float* g;         // its gain, or NULL: plain copy (biases and other un-normalised parameters)
+  float* w;               // destination row
+  float* inv;             // 1/||v|| destination, or NULL
+  int64_t len;
+};
+
+__global__ void __launch_bounds__(64)
+weight_norm_multi_kernel(int n_rows, const WnRow* __restrict__ rows) {
+  const WnRow r = rows[blockIdx.x];
+  const int len = (int)r.len;
+  if (r.g == nullptr) {
+    for (int k = threadIdx.x; k < len; k += 64) r.w[k] = r.v[k];
+    return;
+  }
+  float ss = 0.0f;
+  for (int k = threadIdx.x; k < len; k += 64) { float a = r.v[k]; ss += a * a; }
+  ss = wave_sum(ss);
+  const float nrm = sqrtf(ss);
+  const float scale = r.g[0] / nrm;
+  for (int k = threadIdx.x; k < len; k += 64) r.w[k] = r.v[k] * scale;
+  if (r.inv && threadIdx.x == 0) r.inv[0] = 1.0f / nrm;
+}
+
+struct WnBwdRow {
+  const float* v;         // weight_v row
+  const float* g;         // its gain
+  const float* inv;       // its 1/||v||
+  const float* dW;        // gradient of the effective row, replica 0
+  const float* db_rep;    // bias-gradient element of this row, replica 0 (or NULL)
+  float* dv;              // outputs (overwritten)
+  float* dg;
+  float* db_out;          // (or NULL)
+  int64_t len, reps, rep_stride, db_stride;
+};
+
+__global__ void __launch_bounds__(64)
+weight_norm_bwd_multi_kernel(int n_rows, const WnBwdRow* __restrict__ rows) {
+  const WnBwdRow r = rows[blockIdx.x];
+  const int len = (int)r.len, reps = (int)r.reps;
+  auto dw_at = [&](int k) {
+    float s = r.dW[k];
+    for (int q = 1; q < reps; ++q) s += r.dW[q * r.rep_stride + k];
+    return s;
+  };
+  float dot = 0.0f;
+  for (int k = threadIdx.x; k < len; k += 64) dot += dw_at(k) * r.v[k];
+  dot = wave_sum(dot);
+  const float inv = r.inv[0];
+  const float gg = r.g[0];
+  const float c1 = gg * inv;
+  const float c2 = gg * dot * inv * inv * inv;
+  for (int k = threadIdx.x; k < len; k += 64) r.dv[k] = c1 * dw_at(k) - c2 * r.v[k];
+  if (threadIdx.x == 0) {
+    r.dg[0] = dot * inv;
+    if (r.db_out != nullptr) {
+      float s = 0.0f;
+      for (int q = 0; q < reps; ++q) s += r.db_rep[q * r.db_stride];
+      r.db_out[0] = s;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- pooling --------------
 __global__ void __launch_bounds__(256)
 meansum_pool_kernel(int N, int H, const float* __restrict__ x, int64_t x_ld, const float* __restrict__ maskf,
@@ -546,6 +613,20 @@ extern "C" int mmb_weight_norm(int n_rows, const int32_t* row_off, const int32_t
   hipLaunchKernelGGL(weight_norm_kernel, dim3(n_rows), dim3(64), 0, as_stream(stream), n_rows, row_off, row_len, v,
                      g, W, inv_norm);
   return check_launch("mmb_weight_norm");
+}
+
+extern "C" int mmb_weight_norm_multi(int n_rows, const void* rows, void* stream) {
+  MMB_REQUIRE(n_rows > 0 && rows, "mmb_weight_norm_multi: empty table");
+  hipLaunchKernelGGL(weight_norm_multi_kernel, dim3(n_rows), dim3(64), 0, as_stream(stream), n_rows,
+                     reinterpret_cast<const WnRow*>(rows));
+  return check_launch("mmb_weight_norm_multi");
+}
+
+extern "C" int mmb_weight_norm_bwd_multi(int n_rows, const void* rows, void* stream) {
+  MMB_REQUIRE(n_rows > 0 && rows, "mmb_weight_norm_bwd_multi: empty table");
+  hipLaunchKernelGGL(weight_norm_bwd_multi_kernel, dim3(n_rows), dim3(64), 0, as_stream(stream), n_rows,
+                     reinterpret_cast<const WnBwdRow*>(rows));
+  return check_launch("mmb_weight_norm_bwd_multi");
 }
 
 extern "C" int mmb_weight_norm_bwd_rep(int n_rows, const int32_t* row_off, const int32_t* row_len, const float* v,

@@ -97,39 +97,45 @@ def _encoder(pl, enc, tseg, x_local, x_global, out):
     return out, x_global
 
 
+def _plan_forward(model, pl, temb, cont, disc, hc, hd):
+    """Lay out every activation of one training forward (slots in kernel order, tape records in layered order)."""
+    enc = model.encoder
+    dev = pl.dev
+    H0, H1, H2, half = enc.dims
+    tseg = (temb, SEG_JET_MASK)
+    both = torch.empty(pl.M, H0 + H1, dtype=torch.float32, device=dev)
+    h1, g1 = _encoder(pl, enc.continuous_encoder, tseg, cont, temb, both[:, :H0])
+    h2, g2 = _encoder(pl, enc.discrete_encoder, tseg, disc, temb, both[:, H0:])
+    g = pl.jets(g1.shape[1] + g2.shape[1])
+    pl.tape.append(("cat", [g1, g2], g))
+    f = torch.empty(pl.M, H2, dtype=torch.float32, device=dev)
+    _encoder(pl, enc.fused_encoder, tseg, both, g, f)
+    split = (H2 + 1) // 2
+    f1, f2 = f[:, :split], f[:, split:]
+    for head, fi, hi, y in ((enc.continuous_head, f1, h1, hc), (enc.discrete_head, f2, h2, hd)):
+        pre, h = pl.rows(head["0"].dim_out), pl.rows(head["0"].dim_out)
+        r0 = pl.linear(head["0"], pl.N, [tseg, (fi, SEG_ROW), (hi, SEG_ROW)], act="gelu", pre=pre, y1=h)
+        r2 = pl.linear(head["2"], pl.N, [(h, SEG_ROW)], y1=y)
+        pl.heads.append({"0": r0, "2": r2})
+    pl.both_width = H0 + H1
+    pl.table = torch.tensor(pl.slots, dtype=torch.int64).to(dev, non_blocking=True)
+    pl.keep = (both, f, g)
+
+
 def forward(model, pack, loc, x, k, tape, seed, offset0):
     """-> heads.  loc: the LocalState of embedder.embed (its tape entry is already recorded); x, k: the
     raw bridge state the kernel embeds itself."""
-    enc = model.encoder
     mi = loc.mi
     B, N = mi.B, mi.N
     dev = x.device
     drop_p = float(model.config.encoder.dropout or 0.0) if model.training else 0.0
     pl = _Plan(B, N, dev, tape, drop_p, offset0)
-    H0, H1, H2, half = enc.dims
-    tseg = (loc.temb, SEG_JET_MASK)
-    both = torch.empty(pl.M, H0 + H1, dtype=torch.float32, device=dev)
-    h1, g1 = _encoder(pl, enc.continuous_encoder, tseg, loc.cont_rows, loc.temb, both[:, :H0])
-    h2, g2 = _encoder(pl, enc.discrete_encoder, tseg, loc.disc_rows, loc.temb, both[:, H0:])
-    g = pl.jets(g1.shape[1] + g2.shape[1])
-    tape.append(("cat", [g1, g2], g))
-    f = torch.empty(pl.M, H2, dtype=torch.float32, device=dev)
-    _encoder(pl, enc.fused_encoder, tseg, both, g, f)
-    split = (H2 + 1) // 2
-    f1, f2 = f[:, :split], f[:, split:]
-    heads = []
-    for head, fi, hi in ((enc.continuous_head, f1, h1), (enc.discrete_head, f2, h2)):
-        pre, h = pl.rows(head["0"].dim_out), pl.rows(head["0"].dim_out)
-        heads.append((head, [tseg, (fi, SEG_ROW), (hi, SEG_ROW)], pre, h))
-    table = torch.tensor(pl.slots, dtype=torch.int64).to(dev, non_blocking=True)
-    hc, hd = fused_epic.train_forward(pack, mi, x, k, loc.temb, table, len(pl.slots), drop_p, seed, offset0)
-    for (head, segs, pre, h), y in zip(heads, (hc, hd)):
-        r0 = pl.linear(head["0"], N, segs, act="gelu", pre=pre, y1=h)
-        r2 = pl.linear(head["2"], N, [(h, SEG_ROW)], y1=y)
-        pl.heads.append({"0": r0, "2": r2})
-    pl.pack, pl.mi, pl.loc, pl.seed = pack, mi, loc, seed
-    pl.both_width = H0 + H1
-    pl.keep = (table, both, f, g)
+    hc = torch.empty(B * N, 3, dtype=torch.float32, device=dev)
+    hd = torch.empty(B * N, 8, dtype=torch.float32, device=dev)
+    _plan_forward(model, pl, loc.temb, loc.cont_rows, loc.disc_rows, hc, hd)
+    fused_epic.train_forward(pack, mi, x, k, loc.temb, pl.table, len(pl.slots), drop_p, seed, offset0, hc, hd)
+    pl.pack, pl.mi, pl.seed = pack, mi, seed
+    pl.embed = next(e for e in tape if e[0] == "embed")
     tape.append(("fused_plan", pl))
     return TensorMultiModal(None, hc.view(B, N, -1), hd.view(B, N, -1), loc.mask)
 
@@ -147,14 +153,10 @@ class _Grads:
         return None if t is None else self.by_id.get(id(t))
 
 
-def backward(model, pl, d_hc, d_hd):
-    """Parameter gradients of the fused training forward `pl` given the head gradients (B,N,3), (B,N,8)."""
-    from encoders import backward as bw
-    from mmb_hip import ops
+def _plan_backward(pl, d_heads, cont_width):
+    """Slots of the backward kernel (its walking order) + the weight-gradient jobs (record, dZ, column sums)."""
     B, N, M, dev = pl.B, pl.N, pl.M, pl.dev
-    pack, mi = pl.pack, pl.mi
-    slots = []
-    jobs = []                         # (record, dZ, S)
+    slots, jobs = [], []
 
     def rows(w):
         t = torch.empty(M, w, dtype=torch.float32, device=dev)
@@ -171,9 +173,8 @@ def backward(model, pl, d_hc, d_hd):
         return t
 
     W2 = pl.both_width
-    Et = pl.loc.temb.shape[1]
+    Et = pl.enc[0]["out"]["segs"][0][0].shape[1]
     d_f, d_hb, d_both, d_temb = rows(W2), rows(W2), rows(W2), jets(Et)
-    d_heads = (d_hc.reshape(M, -1).contiguous(), d_hd.reshape(M, -1).contiguous())
     for hr, dh in zip(pl.heads, d_heads):
         use(dh)
         use(hr["0"]["pre"])
@@ -221,19 +222,191 @@ def backward(model, pl, d_hc, d_hd):
         dz_p0, S_p0 = rows(Hb), jets(Hb)
         jobs.extend([(pr["q2"], dz_q2, None), (pr["q0"], dz_q0, None), (pr["p2"], dz_p2, None), (pr["p0"], dz_p0, S_p0)])
         if br == 0:
-            d_cont = rows(pl.loc.cont_rows.shape[1])
+            d_cont = rows(cont_width)
     table = torch.tensor(slots, dtype=torch.int64).to(dev, non_blocking=True)
+    return {"table": table, "n": len(slots), "jobs": jobs, "d_temb": d_temb, "d_cont": d_cont,
+            "keep": (d_f, d_hb, d_both)}
+
+
+def _embed_grads(pl_embed, mi, d_temb, d_cont):
+    from encoders import backward as bw
+    gs = _Grads()
+    gs.put(pl_embed[4], d_temb)
+    if pl_embed[5] is not None:
+        gs.put(pl_embed[5], d_cont)
+    bw._embed_bwd(pl_embed, gs, mi)
+
+
+def backward(model, pl, d_hc, d_hd):
+    """Parameter gradients of the fused training forward `pl` given the head gradients (B,N,3), (B,N,8)."""
+    if isinstance(pl, WorkspaceStep):
+        return pl.ws.backward(model, pl, d_hc, d_hd)
+    from encoders import backward as bw
+    M, dev = pl.M, pl.dev
+    pack, mi = pl.pack, pl.mi
+    d_heads = (d_hc.reshape(M, -1).contiguous(), d_hd.reshape(M, -1).contiguous())
+    bp = _plan_backward(pl, d_heads, pl.embed[5].shape[1])
     pbwd = fused_epic.packed_bwd(pack, fused_epic.params_version(model))
-    fused_epic.train_backward(pack, pbwd, mi, table, len(slots), pl.drop_p, pl.seed, pl.offset0)
+    fused_epic.train_backward(pack, pbwd, mi, bp["table"], bp["n"], pl.drop_p, pl.seed, pl.offset0)
     # ---- parameter gradients: dW = dZ^T X per segment (broadcast segments: column sums, M = B rows), weight norm
+    jobs = bp["jobs"]
     n_acc = sum(bw.GW_REPLICAS * (r["layer"].weight_v.numel() + r["layer"].weight_v.shape[0] + 8) for r, _, _ in jobs)
     arena = bw.Arena(n_acc, dev)
     touched = set()
     for r, dZ, S in jobs:
         bw.param_grads(r["layer"], r["segs"], dZ, S, S, arena, touched)
-    emb = next(e for e in pl.tape if e[0] == "embed")
-    gs = _Grads()
-    gs.put(emb[4], d_temb)
-    if emb[5] is not None:
-        gs.put(emb[5], d_cont)
-    bw._embed_bwd(emb, gs, mi)
+    _embed_grads(pl.embed, mi, bp["d_temb"], bp["d_cont"])
+
+
+# ------------------------------------------------------------------------------------------------------
+class WorkspaceStep:
+    """What one training step leaves on the tape for the reverse pass."""
+
+    def __init__(self, ws, mi, embed, drop_p, seed, offset0):
+        self.ws, self.mi, self.embed, self.drop_p, self.seed, self.offset0 = ws, mi, embed, drop_p, seed, offset0
+
+
+class Workspace:
+    """Persistent buffers and device tables of the fused training step for one (B, N): the activations of the
+    forward, every dZ of the backward, the weight-gradient accumulators, and the tables of the multi-problem
+    launches (weight gradients per tile class, weight-norm backward).  A step is then ~25 launches and no
+    allocation: embed, 3 copies, forward, loss, 2 scalings, backward, one memset, <= 8 + 2 weight-gradient
+    launches, one weight-norm backward, the embedding gradients.  The step's activations are overwritten by
+    the next step: the reverse pass of a step must run before the next forward (the training loop's order)."""
+
+    def __init__(self, model, pack, B, N, dev):
+        from encoders import backward as bw
+        from mmb_hip import ops
+        e = model.config.encoder
+        M = B * N
+        self.key = (B, N, str(dev))
+        self.temb = torch.empty(B, e.dim_emb_time, dtype=torch.float32, device=dev)
+        self.cont = torch.empty(M, e.dim_emb_continuous, dtype=torch.float32, device=dev)
+        self.disc = torch.empty(M, e.dim_emb_discrete, dtype=torch.float32, device=dev)
+        self.d_hc = torch.empty(M, 3, dtype=torch.float32, device=dev)
+        self.d_hd = torch.empty(M, 8, dtype=torch.float32, device=dev)
+        pl = _Plan(B, N, dev, [], 0.0, 0)
+        _plan_forward(model, pl, self.temb, self.cont, self.disc, None, None)
+        self.pl = pl
+        self.bp = _plan_backward(pl, (self.d_hc, self.d_hd), self.cont.shape[1])
+        # ---- weight-gradient problems and their accumulators
+        jobs = self.bp["jobs"]
+        sizes = []
+        for r, dZ, S in jobs:
+            Mr, Nout = dZ.shape
+            R = bw.GW_REPLICAS if Mr >= 16384 else 1
+            Kall = r["layer"].dim_in
+            sizes.append((R, Nout, Kall))
+        pad4 = lambda n: n + (-n) % 4
+        total = sum(R * pad4(Nout * Kall) + R * pad4(Nout) for R, Nout, Kall in sizes)
+        self.arena = torch.zeros(total, dtype=torch.float32, device=dev)
+        probs, self.generic, self.layers = {}, [], []
+        off = 0
+        for (r, dZ, S), (R, Nout, Kall) in zip(jobs, sizes):
+            dWr = self.arena[off:off + R * pad4(Nout * Kall)].view(R, pad4(Nout * Kall))
+            off += R * pad4(Nout * Kall)
+            dbr = self.arena[off:off + R * pad4(Nout)].view(R, pad4(Nout))
+            off += R * pad4(Nout)
+            dW = dWr[0, :Nout * Kall].view(Nout, Kall)
+            koff, first = 0, True
+            for t, kind in r["segs"]:
+                Ks = t.shape[1]
+                dWs = dW[:, koff:koff + Ks]
+                row_seg = kind == SEG_ROW
+                Z = dZ if row_seg else S
+                db = dbr[0] if (row_seg and first) else None
+                reps = R if row_seg else 1
+                if row_seg:
+                    first = False
+                if ops.gw_fast(t, Z):
+                    cls = ops.gw_class(Ks, Nout)
+                    lst = probs.setdefault(cls, [[], 0])
+                    rec, n = ops.gw_record(t, Z, dWs, db, reps, dWr.stride(0), dbr.stride(0), lst[1])
+                    lst[0].append(rec)
+                    lst[1] += n
+                else:
+                    self.generic.append((t, Z, dWs, db, reps, dWr.stride(0), dbr.stride(0)))
+                koff += Ks
+            self.layers.append((r["layer"], dWr, dbr, R))
+        self.gw = [(cls, torch.tensor(recs, dtype=torch.int64).to(dev), len(recs), nblk)
+                   for cls, (recs, nblk) in sorted(probs.items())]
+        self.pack = pack
+        self.grad_ptrs = None
+        self.own_grads = None
+        self.inv_base = None
+
+    # ---- weight-norm backward table: rebuilt whenever a parameter's .grad buffer or storage moved
+    def _params(self):
+        for layer, _, _, _ in self.layers:
+            yield layer.weight_v
+            yield layer.weight_g
+            yield layer.bias
+
+    def _wn_table(self, model):
+        ptrs = tuple((p.data_ptr(), -1 if p.grad is None else p.grad.data_ptr()) for p in self._params())
+        if ptrs == self.grad_ptrs:
+            return
+        missing = [p for p in self._params() if p.grad is None or not p.grad.is_contiguous()]
+        if missing:                                        # no flat bucket: own gradient buffers
+            flat = torch.zeros(sum(p.numel() for p in missing), dtype=torch.float32, device=self.arena.device)
+            o = 0
+            for p in missing:
+                p.grad = flat[o:o + p.numel()].view_as(p)
+                o += p.numel()
+            self.own_grads = flat
+        ar = lambda n: torch.arange(n, dtype=torch.int64)
+        recs = []
+        for layer, dWr, dbr, R in self.layers:
+            W, inv = layer.weight(want_inv=True)
+            O, K = layer.dim_out, layer.dim_in
+            r = torch.empty(O, 12, dtype=torch.int64)
+            r[:, 0] = layer.weight_v.data_ptr() + 4 * K * ar(O)
+            r[:, 1] = layer.weight_g.data_ptr() + 4 * ar(O)
+            r[:, 2] = inv.data_ptr() + 4 * ar(O)
+            r[:, 3] = dWr.data_ptr() + 4 * K * ar(O)
+            r[:, 4] = dbr.data_ptr() + 4 * ar(O)
+            r[:, 5] = layer.weight_v.grad.data_ptr() + 4 * K * ar(O)
+            r[:, 6] = layer.weight_g.grad.data_ptr() + 4 * ar(O)
+            r[:, 7] = layer.bias.grad.data_ptr() + 4 * ar(O)
+            r[:, 8], r[:, 9], r[:, 10], r[:, 11] = K, R, dWr.stride(0), dbr.stride(0)
+            recs.append(r)
+        self.wn_rows = torch.cat(recs).to(self.arena.device)
+        self.inv_base = self.pack["inv"].data_ptr()      # (every layer's inv is a slice of it after refresh_flat)
+        self.grad_ptrs = tuple((p.data_ptr(), p.grad.data_ptr()) for p in self._params())
+
+    def forward(self, model, loc, x, k, tape, seed, offset0):
+        mi = loc.mi
+        B, N = mi.B, mi.N
+        dev = x.device
+        drop_p = float(model.config.encoder.dropout or 0.0) if model.training else 0.0
+        self.temb.copy_(loc.temb)
+        self.cont.copy_(loc.cont_rows)
+        self.disc.copy_(loc.disc_rows)
+        hc = torch.empty(B * N, 3, dtype=torch.float32, device=dev)
+        hd = torch.empty(B * N, 8, dtype=torch.float32, device=dev)
+        pl = self.pl
+        fused_epic.train_forward(self.pack, mi, x, k, self.temb, pl.table, len(pl.slots), drop_p, seed, offset0, hc, hd)
+        embed = next(e for e in tape if e[0] == "embed")
+        tape.append(("fused_plan", WorkspaceStep(self, mi, embed, drop_p, seed, offset0)))
+        return TensorMultiModal(None, hc.view(B, N, -1), hd.view(B, N, -1), loc.mask)
+
+    def backward(self, model, st, d_hc, d_hd):
+        from mmb_hip import ops
+        M = self.pl.M
+        self.d_hc.copy_(d_hc.reshape(M, -1))
+        self.d_hd.copy_(d_hd.reshape(M, -1))
+        pack = self.pack
+        pbwd = fused_epic.packed_bwd(pack, fused_epic.params_version(model))
+        bp = self.bp
+        fused_epic.train_backward(pack, pbwd, st.mi, bp["table"], bp["n"], st.drop_p, st.seed, st.offset0)
+        self.arena.zero_()
+        for cls, table, n, nblk in self.gw:
+            ops.grad_weight_rows_multi(cls, table, n, nblk)
+        for X, Z, dWs, db, reps, rs, ds in self.generic:
+            ops.grad_weight_rows(X, Z, dWs, db, replicas=reps, rep_stride=rs, db_stride=ds)
+        if self.inv_base != pack["inv"].data_ptr():
+            self.grad_ptrs = None
+        self._wn_table(model)
+        ops.weight_norm_bwd_multi(self.wn_rows, self.wn_rows.shape[0])
+        # the embed entry references this step's own (B,Et)/(B*N,Ec) tensors: gradients go by identity
+        _embed_grads(st.embed, st.mi, bp["d_temb"], bp["d_cont"])

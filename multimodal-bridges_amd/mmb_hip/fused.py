@@ -84,7 +84,7 @@ class _RealSource:
     def lin(self, l):
         return l
 
-    def tensor(self, getter):
+    def tensor(self, getter, obj=None):
         return getter()
 
 
@@ -96,22 +96,27 @@ class _IndexSource:
 
     def __init__(self, device):
         self.n, self.getters, self.device = 0, [], device
+        self.items = []               # (kind, object, offset in the flat buffer): what refresh_flat() must produce
 
-    def _idx(self, shape, getter):
+    def _idx(self, shape, getter, kind, obj):
         numel = 1
         for d in shape:
             numel *= d
         t = (torch.arange(numel, device=self.device, dtype=torch.float32) + float(self.n + 1)).view(shape)
+        self.items.append((kind, obj, self.n))
         self.n += numel
         assert self.n < (1 << 24), "gather map indices must stay exact in fp32"
         self.getters.append(getter)
         return t
 
     def lin(self, l):
-        return _IdxLin(self._idx((l.dim_out, l.dim_in), l.weight), self._idx((l.dim_out,), l.bias.detach))
+        return _IdxLin(self._idx((l.dim_out, l.dim_in), l.weight, "wn", l),
+                       self._idx((l.dim_out,), l.bias.detach, "copy", l.bias))
 
-    def tensor(self, getter):
-        return self._idx(tuple(getter().shape), getter)
+    def tensor(self, getter, obj=None):
+        """obj: the nn.Parameter (plain copy) or weight-normed module (rows normalised) behind the getter"""
+        kind = "copy" if isinstance(obj, torch.nn.Parameter) else "wn"
+        return self._idx(tuple(getter().shape), getter, kind, obj)
 
 
 class _Packer:
@@ -230,6 +235,8 @@ def pack_model(model):
     idx = imap.long() - 1
     pack["gather"] = torch.where(idx < 0, torch.full_like(idx, src.n), idx)       # padding -> the trailing zero
     pack["getters"] = src.getters
+    pack["items"], pack["n_flat"] = src.items, src.n
+    pack["flat"] = None                                    # persistent [all sources | 0], see refresh_flat
     pack["zero"] = torch.zeros(1, dtype=torch.float32, device=imap.device)
     # backward weights (training): same sources, so the same flat buffer feeds a second gather
     srcb = _IndexSource(imap.device)
@@ -252,7 +259,7 @@ def _tail_sources(model):
 def packed_bwd(pack, version):
     """Backward parameter buffer for the current parameter version (one cat + one index_select)."""
     if pack["bwd_version"] != version:
-        flat = torch.cat([g().reshape(-1) for g in pack["getters"]] + [pack["zero"]])
+        flat = refresh_flat(pack, version)
         if pack["packed_bwd"] is None:
             pack["packed_bwd"] = flat.index_select(0, pack["gather_bwd"])
         else:
@@ -300,9 +307,78 @@ def _pack_multi_bwd(model, src):
     return torch.cat(pk.chunks), desc
 
 
-def repack(pack):
+def _flat_rows(pack):
+    """Device table of mmb_weight_norm_multi: one record per row of every source -> its place in pack["flat"]."""
+    dev = pack["packed"].device
+    flat, inv = pack["flat"], pack["inv"]
+    recs, ioff, ptrs = [], 0, []
+    ar = lambda n: torch.arange(n, dtype=torch.int64)
+    for kind, obj, off in pack["items"]:
+        if kind == "copy":
+            p = obj.detach()
+            recs.append(torch.tensor([[p.data_ptr(), 0, flat.data_ptr() + 4 * off, 0, p.numel()]], dtype=torch.int64))
+            ptrs.append(p.data_ptr())
+            continue
+        v, g = obj.weight_v.detach(), obj.weight_g.detach()
+        O, K = v.shape
+        r = torch.empty(O, 5, dtype=torch.int64)
+        r[:, 0] = v.data_ptr() + 4 * K * ar(O)
+        r[:, 1] = g.data_ptr() + 4 * ar(O)
+        r[:, 2] = flat.data_ptr() + 4 * (off + K * ar(O))
+        r[:, 3] = inv.data_ptr() + 4 * (ioff + ar(O))
+        r[:, 4] = K
+        recs.append(r)
+        ptrs += [v.data_ptr(), g.data_ptr()]
+        ioff += O
+    pack["flat_rows"] = torch.cat(recs).to(dev)
+    pack["flat_ptrs"] = tuple(ptrs)
+
+
+def _source_ptrs(pack):
+    out = []
+    for kind, obj, off in pack["items"]:
+        if kind == "copy":
+            out.append(obj.data_ptr())
+        else:
+            out += [obj.weight_v.data_ptr(), obj.weight_g.data_ptr()]
+    return tuple(out)
+
+
+def refresh_flat(pack, version):
+    """pack["flat"] = [effective weights, biases, embedding parameters | 0] for the current parameter values: ONE
+    launch (mmb_weight_norm_multi) instead of one weight-norm launch per layer; every layer's weight() cache is
+    pointed at its slice, so nothing else re-normalises this parameter version."""
+    if pack.get("flat_version") == version:
+        return pack["flat"]
+    from . import ops
+    dev = pack["packed"].device
+    if pack["flat"] is None:
+        pack["flat"] = torch.zeros(pack["n_flat"] + 1, dtype=torch.float32, device=dev)
+        n_inv = sum(obj.weight_v.shape[0] for kind, obj, _ in pack["items"] if kind == "wn")
+        pack["inv"] = torch.empty(n_inv, dtype=torch.float32, device=dev)
+        pack["flat_ptrs"] = None
+    if pack["flat_ptrs"] != _source_ptrs(pack):            # first use, or a parameter's storage moved
+        _flat_rows(pack)
+    ops.weight_norm_multi(pack["flat_rows"], pack["flat_rows"].shape[0])
+    flat, inv, ioff = pack["flat"], pack["inv"], 0
+    for kind, obj, off in pack["items"]:
+        if kind != "wn":
+            continue
+        v, g = obj.weight_v, obj.weight_g
+        O, K = v.shape
+        W = flat[off:off + O * K].view(O, K)
+        if hasattr(obj, "dim_in"):                         # WNLinear
+            obj._cache = ((v._version, g._version, v.data_ptr(), g.data_ptr()), W, inv[ioff:ioff + O])
+        else:                                              # WNEmbedding
+            obj._cache = ((v._version, g._version, v.data_ptr()), W)
+        ioff += O
+    pack["flat_version"] = version
+    return flat
+
+
+def repack(pack, version):
     """Refresh the packed parameter buffer after an optimizer step (same architecture, new values)."""
-    flat = torch.cat([g().reshape(-1) for g in pack["getters"]] + [pack["zero"]])
+    flat = refresh_flat(pack, version)
     torch.index_select(flat, 0, pack["gather"], out=pack["packed"])
     pack["time_parts"] = [l.weight()[:, :n_t] for l, n_t in pack["time_lins"]]
     return pack
@@ -345,9 +421,9 @@ def _pack_multi(model, variant, src):
     for head in (enc.continuous_head, enc.discrete_head):
         pk.particle_layer(L(head["0"]), Et, half + H0, 0)
         pk.particle_layer(L(head["2"]), 0, H0, 0)
-    off_cw = pk.add(src.tensor(emb.continuous_embedding.weight.detach))
-    off_cb = pk.add(src.tensor(emb.continuous_embedding.bias.detach))
-    off_table = pk.add(src.tensor(emb.discrete_embedding.table))
+    off_cw = pk.add(src.tensor(emb.continuous_embedding.weight.detach, emb.continuous_embedding.weight))
+    off_cb = pk.add(src.tensor(emb.continuous_embedding.bias.detach, emb.continuous_embedding.bias))
+    off_table = pk.add(src.tensor(emb.discrete_embedding.table, emb.discrete_embedding))
     packed = torch.cat(pk.chunks)
     desc = torch.tensor(pk.desc, dtype=torch.int32, device=dev).reshape(-1)
     return {"kind": "multi", "packed": packed, "time_lins": pk.time_lins, "desc": desc, "variant": variant, "nb_branch": enc.continuous_encoder.num_blocks,
@@ -385,13 +461,13 @@ def forward(pack, mi, x, k, temb, which, temb_stride=None):
     return hc, hd
 
 
-def train_forward(pack, mi, x, k, temb, slots, n_slots, drop_p, seed, offset0):
+def train_forward(pack, mi, x, k, temb, slots, n_slots, drop_p, seed, offset0, hc=None, hd=None):
     """Training forward: both heads + every activation of the tape (encoders/fused_train.py) -> HBM.
     slots: device int64 tensor (n_slots, 3) of (pointer, row pitch, floats available)."""
     B, N = mi.B, mi.N
     dev = x.device
-    hc = torch.empty(B * N, 3, dtype=torch.float32, device=dev)
-    hd = torch.empty(B * N, 8, dtype=torch.float32, device=dev)
+    hc = torch.empty(B * N, 3, dtype=torch.float32, device=dev) if hc is None else hc
+    hd = torch.empty(B * N, 8, dtype=torch.float32, device=dev) if hd is None else hd
     call("mmb_fused_epic_train_forward", pack["variant"], B, N, f32(pack["packed"]), i32(pack["desc"]),
          pack["nb_branch"], pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"], pack["off_table"],
          f32(mi.maskf), i32(mi.counts), f32(x, "x"), i64(k, "k"), f32(temb, "temb"), temb.stride(0),

@@ -412,3 +412,51 @@ def postprocess_(x, k, maskf, scale=None, shift=None, log_pt=False):
     Dc = x.shape[-1] if x is not None else 0
     call("mmb_postprocess", P, Dc, f32(x, "x"), i64(k, "k"), f32(maskf, "maskf"), f32(scale, "scale"),
          f32(shift, "shift"), int(bool(log_pt)), stream())
+
+
+# ---- multi-problem launches (device tables of 8-byte fields, built once per training workspace) ----
+def gw_class(K, Nout):
+    """Tile class (OTb, KTb) mmb_grad_weight_rows picks for a (Nout, K) weight gradient."""
+    ot_all, kt_all = (Nout + 31) // 32, (K + 31) // 32
+    OTb = 4 if ot_all >= 4 else (2 if ot_all >= 2 else 1)
+    KTb = 4 if kt_all >= 4 else (2 if kt_all >= 2 else 1)
+    while OTb * KTb > 8:
+        if KTb >= OTb:
+            KTb //= 2
+        else:
+            OTb //= 2
+    return OTb, KTb
+
+
+def gw_fast(X, dZ):
+    """True when mmb_grad_weight_rows would take its row-streaming path for these operands."""
+    K, Nout = X.shape[1], dZ.shape[1]
+    return (K % 4 == 0 and Nout % 4 == 0 and X.stride(0) % 4 == 0 and dZ.stride(0) % 4 == 0
+            and X.data_ptr() % 16 == 0 and dZ.data_ptr() % 16 == 0 and X.stride(1) == 1 and dZ.stride(1) == 1)
+
+
+def gw_record(X, dZ, dW, db, replicas, rep_stride, db_stride, block_begin):
+    """One GwProb record (list of 18 ints) + the number of blocks it takes."""
+    M, K = X.shape
+    Nout = dZ.shape[1]
+    OTb, KTb = gw_class(K, Nout)
+    rpb = 64 if M <= 16384 else 512
+    nbx = (M + rpb - 1) // rpb
+    nby = ((K + 31) // 32 + KTb - 1) // KTb
+    nbz = ((Nout + 31) // 32 + OTb - 1) // OTb
+    n = nbx * nby * nbz
+    rec = [X.data_ptr(), dZ.data_ptr(), dW.data_ptr(), 0 if db is None else db.data_ptr(), X.stride(0), dZ.stride(0),
+           dW.stride(0), rep_stride, db_stride, M, K, Nout, rpb, replicas, nbx, nby, block_begin, block_begin + n]
+    return rec, n
+
+
+def grad_weight_rows_multi(cls, table, n_probs, total_blocks):
+    call("mmb_grad_weight_rows_multi", cls[0], cls[1], C.c_void_p(table.data_ptr()), n_probs, total_blocks, stream())
+
+
+def weight_norm_multi(table, n_rows):
+    call("mmb_weight_norm_multi", n_rows, C.c_void_p(table.data_ptr()), stream())
+
+
+def weight_norm_bwd_multi(table, n_rows):
+    call("mmb_weight_norm_bwd_multi", n_rows, C.c_void_p(table.data_ptr()), stream())

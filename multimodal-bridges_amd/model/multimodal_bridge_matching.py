@@ -103,6 +103,7 @@ class MultiModalBridgeMatching(nn.Module):
         self.use_fused = True          # per-jet fused kernels when the architecture is eligible
         self.use_fused_training = True # ... also for the taped training forward
         self.use_fused_backward = True # ... and for its reverse pass
+        self._train_ws = None          # persistent buffers/tables of the fused training step
         self._fused_cache = None
 
     # ------------------------------------------------------------------ plumbing
@@ -137,7 +138,7 @@ class MultiModalBridgeMatching(nn.Module):
         elif self._fused_cache[0] != ver:
             old = self._fused_cache[1]
             if old is not None and "gather" in old and old["packed"].device == self.device:
-                self._fused_cache = (ver, fused_epic.repack(old))          # same architecture, new values
+                self._fused_cache = (ver, fused_epic.repack(old, ver))     # same architecture, new values
             else:
                 self._fused_cache = (ver, fused_epic.pack_model(self))
         return self._fused_cache[1]
@@ -190,8 +191,13 @@ class MultiModalBridgeMatching(nn.Module):
             pack = self._fused_pack()
             if pack is not None and pack["kind"] == "multi" and self._pack_serves(pack, state):
                 from encoders import fused_train                        # taped forward in ONE launch
-                return fused_train.forward(self, pack, loc, state.continuous.contiguous(),
-                                           state.discrete.contiguous(), self._tape, self.seed, off)
+                xs, ks = state.continuous.contiguous(), state.discrete.contiguous()
+                if not self.use_fused_backward:                         # (layered reverse pass: per-step buffers)
+                    return fused_train.forward(self, pack, loc, xs, ks, self._tape, self.seed, off)
+                ws = self._train_ws
+                if ws is None or ws.key != (mi.B, mi.N, str(xs.device)) or ws.pack is not pack:
+                    ws = self._train_ws = fused_train.Workspace(self, pack, mi.B, mi.N, xs.device)
+                return ws.forward(self, loc, xs, ks, self._tape, self.seed, off)
         return self.encoder(loc, glob, tape=self._tape, seed=self.seed, offset0=off)
 
     # ------------------------------------------------------------------ training

@@ -324,23 +324,27 @@ def test_fused_training_matches_layered(golden, name, drop):
     t = g.t
     c = lambda a: None if a is None else a.cuda()
     res = {}
-    for mode in ("fused", "fused_forward", "layered"):
+    # fused: persistent workspace + multi-problem launches; fused_step: per-step buffers, fused reverse pass;
+    # fused_forward: fused forward, layered reverse pass
+    for mode in ("fused", "fused_step", "fused_forward", "layered"):
         model.use_fused_training = mode != "layered"
-        model.use_fused_backward = mode == "fused"
+        model.use_fused_backward = False
         model.manual_seed(11)
         state = TensorMultiModal(c(t["time"]), c(t["xt"]), c(t["kt"]), c(t["mask"]))
         model._tape = []
         heads = model.forward(state, None)
         tape, model._tape = model._tape, None
+        model.use_fused_backward = mode == "fused"
         model.manual_seed(11)
         out = model.step_from_state(state, batch_of(g), "train", True)
+        model.use_fused_backward = mode in ("fused", "fused_step")
         model.zero_grad(set_to_none=True)
         out["loss"].backward()
         res[mode] = (heads, out["loss"].detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()
                                                             if p.grad is not None}, tape)
     hl, ll, gl, tl = res["layered"]
     lin_l = [e for e in tl if e[0] == "linear"]
-    for mode in ("fused", "fused_forward"):
+    for mode in ("fused", "fused_step", "fused_forward"):
         hf, lf, gf, tf = res[mode]
         assert any(e[0] == "fused_plan" for e in tf), "the fused training forward did not run"
         lin_f = [e for e in tf if e[0] == "linear"]

@@ -360,3 +360,94 @@ def test_postprocess(ops, transform):
     # discrete-only sample
     out2 = postprocess(TensorMultiModal(None, None, dev(k), dev(mask)), None, None)
     assert torch.equal(out2.discrete.cpu(), want_k)
+
+
+def test_grad_weight_rows_multi(ops):
+    """Many weight-gradient problems per launch (device table, one launch per tile class) against torch matmuls:
+    mixed row counts (per-particle and per-jet), replicas, strided operands, column slices of wider gradients."""
+    g = torch.Generator().manual_seed(77)
+    shapes = [(20000, 64, 64, 8), (1000, 64, 64, 1), (20000, 128, 128, 8), (513, 32, 64, 1), (20000, 64, 128, 8),
+              (700, 144, 64, 1), (20000, 16, 64, 8), (333, 64, 16, 1), (900, 256, 128, 1)]
+    probs, keep = {}, []
+    for M, K, Nout, R in shapes:
+        Xw = torch.randn(M, K + 4, generator=g).cuda()
+        X = Xw[:, 4:]                                    # strided, still 16-byte aligned
+        dZ = torch.randn(M, Nout, generator=g).cuda()
+        dWr = torch.zeros(R, Nout * (K + 8), device="cuda")
+        dbr = torch.zeros(R, Nout, device="cuda")
+        dWs = dWr[0].view(Nout, K + 8)[:, 4:4 + K]
+        assert ops.gw_fast(X, dZ)
+        cls = ops.gw_class(K, Nout)
+        lst = probs.setdefault(cls, [[], 0])
+        rec, n = ops.gw_record(X, dZ, dWs, dbr[0], R, dWr.stride(0), dbr.stride(0), lst[1])
+        lst[0].append(rec)
+        lst[1] += n
+        keep.append((X, dZ, dWr, dbr, K, Nout))
+    assert len(probs) >= 4
+    for cls, (recs, nblk) in sorted(probs.items()):
+        ops.grad_weight_rows_multi(cls, torch.tensor(recs, dtype=torch.int64).cuda(), len(recs), nblk)
+    for X, dZ, dWr, dbr, K, Nout in keep:
+        want = dZ.double().t() @ X.double()
+        got = dWr.double().sum(0).view(Nout, K + 8)
+        close(got[:, 4:4 + K], want, rtol=1e-4, atol=2e-5 * float(want.abs().max()))
+        assert float(got[:, :4].abs().max()) == 0.0 and float(got[:, 4 + K:].abs().max()) == 0.0
+        close(dbr.double().sum(0), dZ.double().sum(0), rtol=1e-4, atol=2e-5 * float(dZ.abs().sum(0).max()))
+
+
+def test_weight_norm_multi_and_backward(ops):
+    """All layers' weight norms (and their reverse) in one launch each against torch autograd of g*v/||v||."""
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 48), (16, 144), (128, 192), (3, 64)]
+    R = 4
+    vs = [torch.randn(O, K, generator=g).cuda().requires_grad_() for O, K in shapes]
+    gs = [(torch.rand(O, 1, generator=g) + 0.5).cuda().requires_grad_() for O, K in shapes]
+    bias = torch.randn(40, generator=g).cuda()
+    n = sum(O * K for O, K in shapes) + 40
+    flat = torch.full((n,), -7.0, device="cuda")
+    inv = torch.zeros(sum(O for O, _ in shapes), device="cuda")
+    ar = lambda m: torch.arange(m, dtype=torch.int64)
+    rows, off, ioff = [], 0, 0
+    for v, gg in zip(vs, gs):
+        O, K = v.shape
+        r = torch.empty(O, 5, dtype=torch.int64)
+        r[:, 0], r[:, 1] = v.data_ptr() + 4 * K * ar(O), gg.data_ptr() + 4 * ar(O)
+        r[:, 2], r[:, 3], r[:, 4] = flat.data_ptr() + 4 * (off + K * ar(O)), inv.data_ptr() + 4 * (ioff + ar(O)), K
+        rows.append(r)
+        off += O * K
+        ioff += O
+    rows.append(torch.tensor([[bias.data_ptr(), 0, flat.data_ptr() + 4 * off, 0, 40]], dtype=torch.int64))
+    table = torch.cat(rows).cuda()
+    ops.weight_norm_multi(table, table.shape[0])
+    off = 0
+    Ws = []
+    for v, gg in zip(vs, gs):
+        O, K = v.shape
+        W = gg * v / v.norm(dim=1, keepdim=True)
+        close(flat[off:off + O * K].view(O, K), W, rtol=1e-5, atol=1e-6)
+        Ws.append(W)
+        off += O * K
+    assert torch.equal(flat[off:], bias)
+    # reverse: dW, db arrive as R replicas
+    brows, outs, ioff = [], [], 0
+    for v, gg, W in zip(vs, gs, Ws):
+        O, K = v.shape
+        dWr = torch.randn(R, O * K + 4, generator=g).cuda()
+        dbr = torch.randn(R, O, generator=g).cuda()
+        dv, dg, db = torch.zeros(O, K, device="cuda"), torch.zeros(O, device="cuda"), torch.zeros(O, device="cuda")
+        r = torch.empty(O, 12, dtype=torch.int64)
+        r[:, 0], r[:, 1], r[:, 2] = v.data_ptr() + 4 * K * ar(O), gg.data_ptr() + 4 * ar(O), inv.data_ptr() + 4 * (ioff + ar(O))
+        r[:, 3], r[:, 4] = dWr.data_ptr() + 4 * K * ar(O), dbr.data_ptr() + 4 * ar(O)
+        r[:, 5], r[:, 6], r[:, 7] = dv.data_ptr() + 4 * K * ar(O), dg.data_ptr() + 4 * ar(O), db.data_ptr() + 4 * ar(O)
+        r[:, 8], r[:, 9], r[:, 10], r[:, 11] = K, R, dWr.stride(0), dbr.stride(0)
+        brows.append(r)
+        outs.append((v, gg, W, dWr, dbr, dv, dg, db))
+        ioff += O
+    table = torch.cat(brows).cuda()
+    ops.weight_norm_bwd_multi(table, table.shape[0])
+    for v, gg, W, dWr, dbr, dv, dg, db in outs:
+        O, K = v.shape
+        dW = dWr[:, :O * K].sum(0).view(O, K)
+        gv, ggr = torch.autograd.grad(W, (v, gg), dW, retain_graph=True)
+        close(dv, gv, rtol=1e-4, atol=1e-5)
+        close(dg, ggr.reshape(-1), rtol=1e-4, atol=1e-5)
+        close(db, dbr.sum(0), rtol=1e-5, atol=1e-5)

@@ -262,5 +262,5 @@ def bench_training(model, config, B, device, dist, steps=10, warmup=3):
     for p in model.parameters():
         p.grad = None
     return {"value": B * world * steps / dt, "unit": "jets/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "global_batch": B * world, "dropout": config.encoder.dropout, "final_loss": float(loss),
+            "global_batch": B * world, "dropout": config.encoder.dropout, "final_loss": float(loss.detach()),
             "includes": "bridge sampling, fwd, loss, bwd, grad all-reduce, clip, AdamW"}

@@ -107,3 +107,56 @@ def test_full_size_training_forward_jet_independence(setup):
         torch.testing.assert_close(fz.discrete, full.discrete, rtol=1e-4, atol=2e-5)
     finally:
         model.use_fused = True
+
+
+def test_full_size_fused_training_step(setup):
+    """Full-size (B=1024, N=128, ragged multiplicities, dropout 0.2) training step: the fused step (one forward
+    launch, one reverse launch, multi-problem weight gradients) against the layered taped step with the same
+    Philox streams -- loss and every parameter gradient; then again on the reused persistent workspace, and once
+    more after a half-size step in between (a step must leave no trace in the next one)."""
+    from tensorclass import TensorMultiModal
+    from datamodules.datasets import DataCoupling
+    model, mask, x0, k0, _ = setup
+    gen = torch.Generator().manual_seed(99)
+    x1 = torch.randn(B, N, 3, generator=gen).cuda() * mask
+    k1 = torch.randint(0, 8, (B, N, 1), generator=gen).cuda() * mask
+    t = (torch.rand(B, generator=gen) * 0.98 + 0.01).cuda()
+    model.train()
+    old_p = model.config.encoder.dropout
+    model.config.encoder.dropout = 0.2
+
+    def step(fused, xs=x0, ks=k0, ms=mask, x1s=x1, k1s=k1, ts=t):
+        model.use_fused_training = model.use_fused_backward = fused
+        model.manual_seed(5)
+        st = TensorMultiModal(ts.reshape(-1, 1, 1), xs, ks, ms)
+        src = TensorMultiModal(None, torch.zeros_like(xs), torch.zeros_like(ks), torch.ones_like(ms))
+        batch = DataCoupling(src, TensorMultiModal(None, x1s, k1s, ms), None)
+        out = model.step_from_state(st, batch, "train", True)
+        model.zero_grad(set_to_none=True)
+        out["loss"].backward()
+        return out["loss"].detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    def check(ga, gb, rtol=2e-3):
+        assert ga.keys() == gb.keys()
+        for n in ga:
+            scale = float(gb[n].abs().max()) + 1e-12
+            torch.testing.assert_close(ga[n], gb[n], rtol=rtol, atol=2e-4 * scale + 1e-7, msg=lambda m: f"{n}: {m}")
+
+    try:
+        lf, gf = step(True)
+        ll, gl = step(False)
+        torch.testing.assert_close(lf, ll, rtol=1e-5, atol=1e-6)
+        check(gf, gl)
+        lf2, gf2 = step(True)                      # same inputs on the reused workspace: bit-identical heads -> same loss
+        assert torch.equal(lf, lf2)
+        check(gf2, gf, rtol=1e-4)                  # (atomics in the weight gradients: order-dependent rounding only)
+        # half the batch, then the full batch again: a smaller step in between must leave no trace
+        h = B // 2
+        step(True, x0[:h], k0[:h], mask[:h], x1[:h], k1[:h], t[:h])
+        lf3, gf3 = step(True)
+        assert torch.equal(lf, lf3)
+        check(gf3, gf, rtol=1e-4)
+    finally:
+        model.config.encoder.dropout = old_p
+        model.use_fused_training = model.use_fused_backward = True
+        model.eval()

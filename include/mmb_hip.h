@@ -342,6 +342,20 @@ int mmb_fused_epic_train_backward(int variant, int B, int N, const float* packed
                                   const void* slots, int n_slots, float drop_p, uint64_t seed, uint64_t offset0,
                                   void* stream);
 
+/* The same pair for the discrete-only UniModalEPiC (multimodal_epic.py:44-64; one EPiC encoder with projection on
+ * cat[t, t, k_emb] whose output layer emits the V logits).  Forward slots: projection 9, layers 6 each.  Backward
+ * slots: [0] d temb (B,Et), d logits (rows,8), column sums of the output layer (B,8), layers last..first, projection. */
+int mmb_fused_uni_train_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
+                                int num_blocks, int use_skip, int off_table,
+                                const float* maskf, const int32_t* counts, const int64_t* k,
+                                const float* temb, int64_t temb_stride,
+                                const void* slots, int n_slots, float drop_p, uint64_t seed, uint64_t offset0,
+                                float* head_d, void* stream);
+int mmb_fused_uni_train_backward(int variant, int B, int N, const float* packed_bwd, const int32_t* desc_bwd,
+                                 int num_blocks, int use_skip, const float* maskf, const int32_t* counts,
+                                 const void* slots, int n_slots, float drop_p, uint64_t seed, uint64_t offset0,
+                                 void* stream);
+
 /* simulate_dynamics (multimodal_bridge_matching.py:227-259) in ONE launch: per grid point
  * [forward -> Euler step on x (solvers.py:21-25)] [forward -> telegraph rates (bridges.py:137-163)
  * -> tau-leap jump (solvers.py:59-81)], final k = argmax of the last rates.  x (B,N,3) and k (B,N)

@@ -451,4 +451,16 @@ struct Dims {
 typedef Dims<32, 16, 16, 64, 16, 3, 8> DimsS3;       // configs/S3_multimodal.yaml
 typedef Dims<16, 8, 8, 32, 8, 3, 8> DimsMid;         // the mm_mid golden / small models
 
+// discrete-only model (UniModalEPiC): one encoder with projection
+template <int ET_, int ED_, int H_, int G_, int V_>
+struct UniDims {
+  static constexpr int ET = ET_, ED = ED_, H = H_, G = G_, V = V_;
+  static constexpr int HT = H / 32;
+  static constexpr int EDT = (ED + 31) / 32;      // input tiles
+  static constexpr int EDP = 32 * EDT;            // padded embedding width
+};
+
+typedef UniDims<128, 128, 128, 16, 8> UniS2;         // configs/S2_discrete.yaml
+typedef UniDims<16, 16, 32, 8, 8> UniMid;            // the uni_mid golden
+
 }  // namespace mmb

@@ -616,21 +616,14 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
 // cat[t, t, trunc(k_emb*mask)] (the time embedding enters twice: multimodal_epic.py:47-54 +
 // epic.py:155 -- both column blocks are summed into one time vector on the host), whose output
 // layer emits the V logits directly (no heads).
-template <int ET_, int ED_, int H_, int G_, int V_>
-struct UniDims {
-  static constexpr int ET = ET_, ED = ED_, H = H_, G = G_, V = V_;
-  static constexpr int HT = H / 32;
-  static constexpr int EDT = (ED + 31) / 32;      // input tiles
-  static constexpr int EDP = 32 * EDT;            // padded embedding width
-};
 
-template <class DM>
+// Training (TR = Train) slots: projection 9, layers 6 each (the V logits of the output layer go to the caller).
+template <class DM, class TR>
 __device__ __forceinline__ void forward_uni(const FusedArgs& A, Lds& L, float4* S, const float* tab, int kp, float m,
-                                            f32x16& hd, int tid) {
+                                            f32x16& hd, int tid, TR& nt) {
   constexpr int HT = DM::HT;
   const int lane = tid & 63, half = lane >> 5;
   int li = 0, ci = 0;
-  NoTrain nt;
   FE_PROF(L, PF_STEP);
   f32x16 td[DM::EDT];
   ffor<DM::EDT>([&](auto tc) { constexpr int t = decltype(tc)::v;
@@ -696,7 +689,42 @@ fused_uni_forward_kernel(FusedArgs A, const int64_t* __restrict__ k, const float
     const int kp = valid ? (int)k[gp] : 0;
     __syncthreads();
     f32x16 hd;
-    forward_uni<DM>(A, L, S, tab, kp, m, hd, tid);
+    NoTrain nt;
+    forward_uni<DM>(A, L, S, tab, kp, m, hd, tid, nt);
+    float lg[8];
+    gather8(hd, lg, lane);
+    if (valid && half == 0) {
+#pragma unroll
+      for (int v = 0; v < 8; ++v) head_d[gp * 8 + v] = lg[v];
+    }
+  }
+}
+
+// training forward of the discrete-only model: logits + every activation of the tape to HBM
+template <class DM>
+__global__ void __launch_bounds__(FE_THREADS, 2)
+fused_uni_train_forward_kernel(FusedArgs A, const int64_t* __restrict__ k, const float* __restrict__ temb,
+                               int64_t temb_stride, const SaveSlot* __restrict__ slots, int n_slots, float drop_p,
+                               uint64_t seed, uint64_t offset0, float* __restrict__ head_d) {
+  static_assert(DM::V == 8, "fused path is instantiated for vocab_size 8");
+  __shared__ Lds L;
+  __shared__ float4 S[DM::HT * 4 * FE_THREADS];
+  __shared__ __attribute__((aligned(16))) float tab[DM::V * DM::EDP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  load_table_uni<DM>(A, tab, tid);
+  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+    __syncthreads();
+    if (tid < DM::ET) L.temb[tid] = temb[(int64_t)b * temb_stride + tid];
+    if (tid == 0) L.cnt = (float)A.counts[b];
+    const int p = 32 * wave + (lane & 31);
+    const bool valid = p < A.N;
+    const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
+    const float m = valid ? A.maskf[gp] : 0.0f;
+    const int kp = valid ? (int)k[gp] : 0;
+    __syncthreads();
+    Train tr{slots, n_slots, 0, b, A.N, p, drop_p, seed, offset0};
+    f32x16 hd;
+    forward_uni<DM>(A, L, S, tab, kp, m, hd, tid, tr);
     float lg[8];
     gather8(hd, lg, lane);
     if (valid && half == 0) {
@@ -731,7 +759,8 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
       __syncthreads();
       A.ctab = Gn.ctab_steps ? Gn.ctab_steps + (int64_t)s * Gn.n_ctab * 128 : nullptr;
       f32x16 hd;
-      forward_uni<DM>(A, L, S, tab, kp, m, hd, tid);
+      NoTrain nt;
+      forward_uni<DM>(A, L, S, tab, kp, m, hd, tid, nt);
       float r[8];
       gather8(hd, r, lane);
       kp = jump_step(r, kp, Gn.times[s], Gn, s == Gn.steps - 1, valid, A.B, A.N, b, p, s, gp);
@@ -740,8 +769,6 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
   }
 }
 
-typedef UniDims<128, 128, 128, 16, 8> UniS2;         // configs/S2_discrete.yaml
-typedef UniDims<16, 16, 32, 8, 8> UniMid;            // the uni_mid golden
 
 
 static int check_fused(const char* name, int B, int N, const void* P, const void* D, const void* maskf,
@@ -826,6 +853,32 @@ extern "C" int mmb_fused_uni_forward(int variant, int B, int N, const float* pac
     hipLaunchKernelGGL(fused_uni_forward_kernel<UniMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k, temb,
                        temb_stride, head_d);
   return check_launch("mmb_fused_uni_forward");
+}
+
+extern "C" int mmb_fused_uni_train_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
+                                           int num_blocks, int use_skip, int off_table, const float* maskf,
+                                           const int32_t* counts, const int64_t* k, const float* temb,
+                                           int64_t temb_stride, const void* slots, int n_slots, float drop_p,
+                                           uint64_t seed, uint64_t offset0, float* head_d, void* stream) {
+  int rc = check_fused("mmb_fused_uni_train_forward", B, N, packed, desc, maskf, counts);
+  if (rc) return rc;
+  MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_uni_train_forward: unknown variant %d", variant);
+  MMB_REQUIRE(k && temb && head_d && slots, "mmb_fused_uni_train_forward: NULL argument");
+  MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_fused_uni_train_forward: dropout p=%f outside [0,1)", drop_p);
+  const int expect = 9 + 6 * num_blocks;
+  MMB_REQUIRE(n_slots == expect, "mmb_fused_uni_train_forward: %d save slots given, the architecture has %d", n_slots,
+              expect);
+  FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), num_blocks, 0, use_skip, 0, 0, off_table, B, N,
+              maskf, counts};
+  const SaveSlot* tab = reinterpret_cast<const SaveSlot*>(slots);
+  const int grid = B < 4096 ? B : 4096;
+  if (variant == 0)
+    hipLaunchKernelGGL(fused_uni_train_forward_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k,
+                       temb, temb_stride, tab, n_slots, drop_p, seed, offset0, head_d);
+  else
+    hipLaunchKernelGGL(fused_uni_train_forward_kernel<UniMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k,
+                       temb, temb_stride, tab, n_slots, drop_p, seed, offset0, head_d);
+  return check_launch("mmb_fused_uni_train_forward");
 }
 
 extern "C" int mmb_fused_uni_generate(int variant, int B, int N, const float* packed, const int32_t* desc,

@@ -69,15 +69,15 @@ __device__ __forceinline__ void mma_go(f32x16 (&acc)[OT], TileFn&& tile, const f
 
 // s = column sums of the dZ tiles over the jet's particles -> LB.svec and row b of the next slot
 template <int HT>
-__device__ __forceinline__ void colsum(const f32x16 (&dz)[HT], LdsB& LB, Slots& sl, int tid) {
+__device__ __forceinline__ void colsum(const f32x16 (&dz)[HT], LdsB& LB, Slots& sl, int tid, int W = 32 * HT) {
   const int lane = tid & 63, wave = tid >> 6;
   pool_partials<HT>(dz, 1.0f, LB.partial, wave, lane);
   __syncthreads();
-  float* dst = sl.row(32 * HT);
+  float* dst = sl.row(W);                                // W: true width of the layer (the slot's row length)
   if (tid < 32 * HT) {
     const float s = (LB.partial[tid] + LB.partial[128 + tid]) + (LB.partial[256 + tid] + LB.partial[384 + tid]);
     LB.svec[tid] = s;
-    if (dst != nullptr) dst[tid] = s;
+    if (dst != nullptr && tid < W) dst[tid] = s;
   }
   __syncthreads();
 }
@@ -107,9 +107,9 @@ struct EpicB {
   template <int OTO>
   static __device__ __forceinline__ void output_bwd(f32x16 (&dx)[HT], const f32x16 (&dout)[OTO], const BDesc o,
                                                     const float* __restrict__ P, const float* add, LdsB& LB, Slots& sl,
-                                                    int tid) {
+                                                    int tid, int ow = 32 * OTO) {
     const int lane = tid & 63;
-    colsum<OTO>(dout, LB, sl, tid);
+    colsum<OTO>(dout, LB, sl, tid, ow);
     auto sv = [&](int k) { return LB.svec[k]; };
     WaveMV<32 * OTO, ET>::template run<MMB_ACT_NONE>(P + o.b, nullptr, sv, LB.dtemb, LB.dtemb, tid);
     WaveMV<32 * OTO, G>::template run<MMB_ACT_NONE>(P + o.c, nullptr, sv, LB.dg, add, tid);
@@ -392,9 +392,82 @@ fused_train_backward_kernel(BwdArgs A) {
   }
 }
 
+// ---- discrete-only model (UniModalEPiC): one encoder with projection whose output layer emits the logits.
+// Slot table: [0] d temb (B,ET); then d logits (rows,8), column sums of the output layer (B,8), layers
+// last..first, projection.
+template <class DM>
+__global__ void __launch_bounds__(FE_THREADS, 2)
+fused_uni_train_backward_kernel(BwdArgs A) {
+  static_assert(DM::V == 8, "fused path is instantiated for vocab_size 8");
+  __shared__ LdsB LB;
+  __shared__ float4 S[DM::HT * 4 * FE_THREADS];
+  constexpr int HT = DM::HT, ET = DM::ET, G = DM::G;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int nb = A.nb_branch;
+  const bool use_skip = A.use_skip != 0;
+  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+    __syncthreads();
+    const int p = 32 * wave + (lane & 31);
+    const bool valid = p < A.N;
+    const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
+    const float m = valid ? A.maskf[gp] : 0.0f;
+    if (tid == 0) LB.cnt = (float)A.counts[b];
+    if (tid < 128) LB.dtemb[tid] = 0.0f;
+    __syncthreads();
+    Slots sl{A.slots, A.n_slots, 1, b, A.N, p, half};
+    const SaveSlot s_dtemb = sl.at(0);
+    const SaveSlot sd = sl.next();
+    f32x16 dx[HT];
+    {
+      f32x16 dout[1];
+      zero_tiles<1>(dout);
+      if (valid && (gp + 1) * sd.ld <= sd.n) {
+        const float4 v = *reinterpret_cast<const float4*>(sd.p + gp * sd.ld + 4 * half);
+        dout[0][0] = v.x; dout[0][1] = v.y; dout[0][2] = v.z; dout[0][3] = v.w;
+      }
+      EpicB<HT, ET, G>::template output_bwd<1>(dx, dout, A.D[4 + 4 * nb], A.P, nullptr, LB, sl, tid, DM::V);
+    }
+    if (use_skip) {
+      f32x16 z;
+      ffor<16>([&](auto rc) { z[decltype(rc)::v] = 0.0f; });
+      ffor<HT>([&](auto tc) { park_tile(S, decltype(tc)::v, z, tid); });
+    }
+    if (tid < G) LB.dgskip[tid] = 0.0f;
+    __syncthreads();
+    for (int i = nb - 1; i >= 0; --i)
+      EpicB<HT, ET, G>::layer_bwd(dx, A.D + 4 + 4 * i, A.P, use_skip, LB, S, sl, m, tid, A.drop_p, A.seed,
+                                  A.offset0 + 2 * (uint64_t)i + 1, A.offset0 + 2 * (uint64_t)i + 2);
+    EpicB<HT, ET, G>::template project_bwd<0>(dx, A.D, A.P, use_skip, LB, S, sl, m, tid);
+    __syncthreads();
+    float* dt = sl.row_of(s_dtemb, ET);
+    if (tid < ET && dt != nullptr) dt[tid] = LB.dtemb[tid];
+  }
+}
+
 }  // namespace mmb
 
 using namespace mmb;
+
+extern "C" int mmb_fused_uni_train_backward(int variant, int B, int N, const float* packed_bwd, const int32_t* desc_bwd,
+                                            int num_blocks, int use_skip, const float* maskf, const int32_t* counts,
+                                            const void* slots, int n_slots, float drop_p, uint64_t seed,
+                                            uint64_t offset0, void* stream) {
+  MMB_REQUIRE(B > 0 && N > 0 && N <= 128, "mmb_fused_uni_train_backward: needs 0 < N <= 128 (got B=%d N=%d)", B, N);
+  MMB_REQUIRE(packed_bwd && desc_bwd && maskf && counts && slots, "mmb_fused_uni_train_backward: NULL argument");
+  MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_uni_train_backward: unknown variant %d", variant);
+  MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_fused_uni_train_backward: dropout p=%f outside [0,1)", drop_p);
+  const int expect = 1 + 2 + num_blocks * (use_skip ? 10 : 9) + 9;
+  MMB_REQUIRE(n_slots == expect, "mmb_fused_uni_train_backward: %d slots given, the architecture has %d", n_slots,
+              expect);
+  BwdArgs A{packed_bwd, reinterpret_cast<const BDesc*>(desc_bwd), num_blocks, 0, use_skip, B, N, maskf,
+            counts, reinterpret_cast<const SaveSlot*>(slots), n_slots, drop_p, seed, offset0};
+  const int grid = B < 4096 ? B : 4096;
+  if (variant == 0)
+    hipLaunchKernelGGL(fused_uni_train_backward_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A);
+  else
+    hipLaunchKernelGGL(fused_uni_train_backward_kernel<UniMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A);
+  return check_launch("mmb_fused_uni_train_backward");
+}
 
 extern "C" int mmb_fused_epic_train_backward(int variant, int B, int N, const float* packed_bwd, const int32_t* desc_bwd,
                                              int nb_branch, int nb_fused_exec, int use_skip, const float* maskf,

@@ -237,7 +237,8 @@ def run_backward(model, tape, heads, d_hc, d_hd, d_s=None, scale=None):
     if plan is not None and getattr(model, "use_fused_backward", True):
         from encoders import fused_train
         if scale is not None:
-            d_hc, d_hd = d_hc * scale, d_hd * scale
+            d_hc = None if d_hc is None else d_hc * scale
+            d_hd = None if d_hd is None else d_hd * scale
             d_s = None if d_s is None else d_s * scale
         fused_train.backward(model, plan, d_hc, d_hd)
         lw = getattr(model.loss_multimode, "loss_weights", None)

@@ -52,14 +52,16 @@ class _Plan:
         return {"layer": layer, "segs": segs, "pre": pre, "y1": y1, "y2": y2}
 
 
-def _encoder(pl, enc, tseg, x_local, x_global, out):
+def _encoder(pl, enc, tseg, x_local, x_global, out, out_slot=True):
+    """x_local: a (rows, width) tensor, or the list of segments the projection concatenates after the time"""
     N = pl.N
     rec = {"proj": None, "layers": [], "skip": None}
     if hasattr(enc, "epic_proj"):
         pr = enc.epic_proj
         H, G = pr.mlp_local["0"].dim_out, pr.mlp_global["2"].dim_out
         pre, h = pl.rows(H), pl.rows(H)
-        p0 = pl.linear(pr.mlp_local["0"], N, [tseg, (x_local, SEG_ROW)], act="gelu", pre=pre, y1=h)
+        loc = x_local if isinstance(x_local, list) else [(x_local, SEG_ROW)]
+        p0 = pl.linear(pr.mlp_local["0"], N, [tseg] + loc, act="gelu", pre=pre, y1=h)
         pre, h2 = pl.rows(H), pl.rows(H)
         p2 = pl.linear(pr.mlp_local["2"], N, [(h, SEG_ROW)], act="gelu", pre=pre, y1=h2)
         pooled = pl.jets(2 * H)
@@ -91,7 +93,8 @@ def _encoder(pl, enc, tseg, x_local, x_global, out):
         l2 = pl.linear(ly.fc_loc2, N, [(lh, SEG_ROW)], res1=x_local, post="lrelu", res2=skip_l, y2=l_out, p=p, off=off)
         rec["layers"].append({"g1": g1, "g2": g2, "l1": l1, "l2": l2})
         x_local, x_global = l_out, g_out
-    pl.slot(out)
+    if out_slot:
+        pl.slot(out)
     rec["out"] = pl.linear(enc.output_layer, N, [tseg, (x_local, SEG_ROW), (x_global, SEG_JET)], y1=out)
     pl.enc.append(rec)
     return out, x_global
@@ -101,6 +104,15 @@ def _plan_forward(model, pl, temb, cont, disc, hc, hd):
     """Lay out every activation of one training forward (slots in kernel order, tape records in layered order)."""
     enc = model.encoder
     dev = pl.dev
+    pl.kind = "uni" if hasattr(enc, "epic") else "multi"
+    if pl.kind == "uni":                                   # UniModalEPiC: cat[t, t, disc] -> one EPiC -> logits
+        tseg = (temb, SEG_JET_MASK)
+        if hd is None:
+            hd = torch.empty(pl.M, model.config.data.vocab_size, dtype=torch.float32, device=dev)
+        _encoder(pl, enc.epic, tseg, [tseg, (disc, SEG_ROW)], temb, hd, out_slot=False)
+        pl.table = torch.tensor(pl.slots, dtype=torch.int64).to(dev, non_blocking=True)
+        pl.keep = ()
+        return
     H0, H1, H2, half = enc.dims
     tseg = (temb, SEG_JET_MASK)
     both = torch.empty(pl.M, H0 + H1, dtype=torch.float32, device=dev)
@@ -127,17 +139,21 @@ def forward(model, pack, loc, x, k, tape, seed, offset0):
     raw bridge state the kernel embeds itself."""
     mi = loc.mi
     B, N = mi.B, mi.N
-    dev = x.device
+    dev = k.device
     drop_p = float(model.config.encoder.dropout or 0.0) if model.training else 0.0
     pl = _Plan(B, N, dev, tape, drop_p, offset0)
-    hc = torch.empty(B * N, 3, dtype=torch.float32, device=dev)
+    uni = pack["kind"] == "uni"
+    hc = None if uni else torch.empty(B * N, 3, dtype=torch.float32, device=dev)
     hd = torch.empty(B * N, 8, dtype=torch.float32, device=dev)
     _plan_forward(model, pl, loc.temb, loc.cont_rows, loc.disc_rows, hc, hd)
-    fused_epic.train_forward(pack, mi, x, k, loc.temb, pl.table, len(pl.slots), drop_p, seed, offset0, hc, hd)
+    if uni:
+        fused_epic.train_forward_uni(pack, mi, k, loc.temb, pl.table, len(pl.slots), drop_p, seed, offset0, hd)
+    else:
+        fused_epic.train_forward(pack, mi, x, k, loc.temb, pl.table, len(pl.slots), drop_p, seed, offset0, hc, hd)
     pl.pack, pl.mi, pl.seed = pack, mi, seed
     pl.embed = next(e for e in tape if e[0] == "embed")
     tape.append(("fused_plan", pl))
-    return TensorMultiModal(None, hc.view(B, N, -1), hd.view(B, N, -1), loc.mask)
+    return TensorMultiModal(None, None if uni else hc.view(B, N, -1), hd.view(B, N, -1), loc.mask)
 
 
 class _Grads:
@@ -151,6 +167,26 @@ class _Grads:
 
     def get(self, t):
         return None if t is None else self.by_id.get(id(t))
+
+
+def _layers_bwd(rec, use, rows, jets, jobs):
+    """slots + jobs of the executed EPiC layers of one encoder, last layer first (the kernel's order)"""
+    for lr in reversed(rec["layers"]):
+        l_out = lr["l2"]["y2"]
+        H = l_out.shape[1]
+        G = lr["g2"]["y1"].shape[1]
+        use(l_out)
+        if rec["skip"] is not None:
+            use(rec["skip"])
+        dz_l2 = rows(H)
+        use(lr["l1"]["y1"])
+        dz_l1, S_l1 = rows(H), jets(H)
+        use(lr["g2"]["y1"])
+        dz_g2 = jets(G)
+        use(lr["g1"]["y1"])
+        dz_g1 = jets(lr["g1"]["y1"].shape[1])
+        jobs.extend([(lr["l2"], dz_l2, None), (lr["l1"], dz_l1, S_l1), (lr["g2"], dz_g2, None),
+                     (lr["g1"], dz_g1, None)])
 
 
 def _plan_backward(pl, d_heads, cont_width):
@@ -172,8 +208,31 @@ def _plan_backward(pl, d_heads, cont_width):
         slots.append(_slot(t))
         return t
 
-    W2 = pl.both_width
     Et = pl.enc[0]["out"]["segs"][0][0].shape[1]
+
+    def proj_bwd(rec, Hb):
+        pr = rec["proj"]
+        use(pr["q2"]["pre"])
+        dz_q2 = jets(pr["q2"]["pre"].shape[1])
+        use(pr["q0"]["pre"])
+        dz_q0 = jets(pr["q0"]["pre"].shape[1])
+        use(pr["p2"]["pre"])
+        dz_p2 = rows(Hb)
+        use(pr["p0"]["pre"])
+        dz_p0, S_p0 = rows(Hb), jets(Hb)
+        jobs.extend([(pr["q2"], dz_q2, None), (pr["q0"], dz_q0, None), (pr["p2"], dz_p2, None), (pr["p0"], dz_p0, S_p0)])
+
+    if pl.kind == "uni":
+        d_temb = jets(Et)
+        rec = pl.enc[0]
+        d_hd = use(d_heads[-1])
+        jobs.append((rec["out"], d_hd, jets(d_hd.shape[1])))
+        _layers_bwd(rec, use, rows, jets, jobs)
+        proj_bwd(rec, rec["proj"]["p2"]["pre"].shape[1])
+        table = torch.tensor(slots, dtype=torch.int64).to(dev, non_blocking=True)
+        return {"table": table, "n": len(slots), "jobs": jobs, "d_temb": d_temb, "d_cont": None, "keep": ()}
+
+    W2 = pl.both_width
     d_f, d_hb, d_both, d_temb = rows(W2), rows(W2), rows(W2), jets(Et)
     for hr, dh in zip(pl.heads, d_heads):
         use(dh)
@@ -184,22 +243,7 @@ def _plan_backward(pl, d_heads, cont_width):
         jobs.append((hr["0"], dz, S))
 
     def layers_bwd(rec):
-        for lr in reversed(rec["layers"]):
-            l_out = lr["l2"]["y2"]
-            H = l_out.shape[1]
-            G = lr["g2"]["y1"].shape[1]
-            use(l_out)
-            if rec["skip"] is not None:
-                use(rec["skip"])
-            dz_l2 = rows(H)
-            use(lr["l1"]["y1"])
-            dz_l1, S_l1 = rows(H), jets(H)
-            use(lr["g2"]["y1"])
-            dz_g2 = jets(G)
-            use(lr["g1"]["y1"])
-            dz_g1 = jets(lr["g1"]["y1"].shape[1])
-            jobs.extend([(lr["l2"], dz_l2, None), (lr["l1"], dz_l1, S_l1), (lr["g2"], dz_g2, None),
-                         (lr["g1"], dz_g1, None)])
+        _layers_bwd(rec, use, rows, jets, jobs)
 
     fe = pl.enc[2]
     jobs.append((fe["out"], d_f, jets(W2)))
@@ -210,17 +254,7 @@ def _plan_backward(pl, d_heads, cont_width):
         Hb = rec["out"]["y1"].shape[1]
         jobs.append((rec["out"], d_both[:, br * Hb:(br + 1) * Hb], jets(Hb)))
         layers_bwd(rec)
-        pr = rec["proj"]
-        G = pr["q2"]["pre"].shape[1]
-        use(pr["q2"]["pre"])
-        dz_q2 = jets(G)
-        use(pr["q0"]["pre"])
-        dz_q0 = jets(pr["q0"]["pre"].shape[1])
-        use(pr["p2"]["pre"])
-        dz_p2 = rows(Hb)
-        use(pr["p0"]["pre"])
-        dz_p0, S_p0 = rows(Hb), jets(Hb)
-        jobs.extend([(pr["q2"], dz_q2, None), (pr["q0"], dz_q0, None), (pr["p2"], dz_p2, None), (pr["p0"], dz_p0, S_p0)])
+        proj_bwd(rec, Hb)
         if br == 0:
             d_cont = rows(cont_width)
     table = torch.tensor(slots, dtype=torch.int64).to(dev, non_blocking=True)
@@ -244,8 +278,8 @@ def backward(model, pl, d_hc, d_hd):
     from encoders import backward as bw
     M, dev = pl.M, pl.dev
     pack, mi = pl.pack, pl.mi
-    d_heads = (d_hc.reshape(M, -1).contiguous(), d_hd.reshape(M, -1).contiguous())
-    bp = _plan_backward(pl, d_heads, pl.embed[5].shape[1])
+    d_heads = tuple(d.reshape(M, -1).contiguous() for d in (d_hc, d_hd) if d is not None)
+    bp = _plan_backward(pl, d_heads, 0 if pl.embed[5] is None else pl.embed[5].shape[1])
     pbwd = fused_epic.packed_bwd(pack, fused_epic.params_version(model))
     fused_epic.train_backward(pack, pbwd, mi, bp["table"], bp["n"], pl.drop_p, pl.seed, pl.offset0)
     # ---- parameter gradients: dW = dZ^T X per segment (broadcast segments: column sums, M = B rows), weight norm
@@ -280,15 +314,17 @@ class Workspace:
         e = model.config.encoder
         M = B * N
         self.key = (B, N, str(dev))
+        self.uni = pack["kind"] == "uni"
         self.temb = torch.empty(B, e.dim_emb_time, dtype=torch.float32, device=dev)
-        self.cont = torch.empty(M, e.dim_emb_continuous, dtype=torch.float32, device=dev)
+        self.cont = None if self.uni else torch.empty(M, e.dim_emb_continuous, dtype=torch.float32, device=dev)
         self.disc = torch.empty(M, e.dim_emb_discrete, dtype=torch.float32, device=dev)
-        self.d_hc = torch.empty(M, 3, dtype=torch.float32, device=dev)
+        self.d_hc = None if self.uni else torch.empty(M, 3, dtype=torch.float32, device=dev)
         self.d_hd = torch.empty(M, 8, dtype=torch.float32, device=dev)
         pl = _Plan(B, N, dev, [], 0.0, 0)
-        _plan_forward(model, pl, self.temb, self.cont, self.disc, None, None)
+        _plan_forward(model, pl, self.temb, self.cont, self.disc, None, self.d_hd if self.uni else None)
         self.pl = pl
-        self.bp = _plan_backward(pl, (self.d_hc, self.d_hd), self.cont.shape[1])
+        d_heads = (self.d_hd,) if self.uni else (self.d_hc, self.d_hd)
+        self.bp = _plan_backward(pl, d_heads, 0 if self.uni else self.cont.shape[1])
         # ---- weight-gradient problems and their accumulators
         jobs = self.bp["jobs"]
         sizes = []
@@ -377,23 +413,27 @@ class Workspace:
     def forward(self, model, loc, x, k, tape, seed, offset0):
         mi = loc.mi
         B, N = mi.B, mi.N
-        dev = x.device
+        dev = k.device
         drop_p = float(model.config.encoder.dropout or 0.0) if model.training else 0.0
         self.temb.copy_(loc.temb)
-        self.cont.copy_(loc.cont_rows)
         self.disc.copy_(loc.disc_rows)
-        hc = torch.empty(B * N, 3, dtype=torch.float32, device=dev)
         hd = torch.empty(B * N, 8, dtype=torch.float32, device=dev)
         pl = self.pl
-        fused_epic.train_forward(self.pack, mi, x, k, self.temb, pl.table, len(pl.slots), drop_p, seed, offset0, hc, hd)
         embed = next(e for e in tape if e[0] == "embed")
         tape.append(("fused_plan", WorkspaceStep(self, mi, embed, drop_p, seed, offset0)))
+        if self.uni:
+            fused_epic.train_forward_uni(self.pack, mi, k, self.temb, pl.table, len(pl.slots), drop_p, seed, offset0, hd)
+            return TensorMultiModal(None, None, hd.view(B, N, -1), loc.mask)
+        self.cont.copy_(loc.cont_rows)
+        hc = torch.empty(B * N, 3, dtype=torch.float32, device=dev)
+        fused_epic.train_forward(self.pack, mi, x, k, self.temb, pl.table, len(pl.slots), drop_p, seed, offset0, hc, hd)
         return TensorMultiModal(None, hc.view(B, N, -1), hd.view(B, N, -1), loc.mask)
 
     def backward(self, model, st, d_hc, d_hd):
         from mmb_hip import ops
         M = self.pl.M
-        self.d_hc.copy_(d_hc.reshape(M, -1))
+        if not self.uni:
+            self.d_hc.copy_(d_hc.reshape(M, -1))
         self.d_hd.copy_(d_hd.reshape(M, -1))
         pack = self.pack
         pbwd = fused_epic.packed_bwd(pack, fused_epic.params_version(model))

@@ -124,6 +124,7 @@ class _Packer:
         self.chunks, self.n, self.desc, self.device = [], 0, [], device
         self.time_parts = []          # W[:, :Et] of every layer that consumes the time embedding, kernel order
         self.time_lins = []
+        self.second = []              # index mode: (offset, indices) of blocks that are ADDED on top (time_twice)
         self.mfma_flops = []          # 2*K_pad*O_pad of every per-particle layer (what the MFMAs execute)
 
     def add(self, t):
@@ -160,12 +161,15 @@ class _Packer:
         if n_t:
             Wt = W[:, :n_t]
             if time_twice:
-                Wt = (Wt + W[:, n_t:2 * n_t]).contiguous()
+                if isinstance(lin, _IdxLin):                 # gather map: the second block goes to a second map
+                    self.second.append((self.n, W[:, n_t:2 * n_t].t().contiguous().reshape(-1)))
+                else:
+                    Wt = (Wt + W[:, n_t:2 * n_t]).contiguous()
                 W = W[:, n_t:]
         wt = self.add(Wt.t()) if n_t else -1
         if n_t:
             self.time_parts.append(Wt)
-            self.time_lins.append((lin, n_t))
+            self.time_lins.append((lin, n_t, time_twice))
         packed_x = self.pack_x(W[:, n_t:n_t + n_x])
         self.mfma_flops.append(2 * packed_x.numel())
         wx = self.add(packed_x)
@@ -178,11 +182,30 @@ class _Packer:
 
     # ---- backward pack (csrc/fused_epic_bwd.hip, BDesc): transposed x-part in fragment order, the time and
     # global-vector column blocks row-major (O,Kseg) -- the [K][O] layout of the kernel's matvec for W^T v
-    def particle_layer_bwd(self, lin, n_t, n_x, n_g):
+    def particle_layer_bwd(self, lin, n_t, n_x, n_g, time_twice=False):
         W = lin.weight()
+        O = W.shape[0]
+        Op = (O + 31) // 32 * 32                              # the kernel's matvecs run over whole 32-row tiles
+
+        def rows(blk):
+            if Op == O:
+                return blk
+            out = torch.zeros(Op, blk.shape[1], device=blk.device)
+            out[:O] = blk
+            return out
+
+        Wt = W[:, :n_t] if n_t else None
+        if time_twice:
+            if isinstance(lin, _IdxLin):
+                self.second.append((None, rows(W[:, n_t:2 * n_t]).contiguous().reshape(-1)))
+            else:
+                Wt = Wt + W[:, n_t:2 * n_t]
+            W = W[:, n_t:]
         a = self.add(self.pack_x(W[:, n_t:n_t + n_x].t()))
-        b = self.add(W[:, :n_t]) if n_t else -1
-        c = self.add(W[:, n_t + n_x:]) if n_g else -1
+        if time_twice and isinstance(lin, _IdxLin):
+            self.second[-1] = (self.n, self.second[-1][1])
+        b = self.add(rows(Wt)) if n_t else -1
+        c = self.add(rows(W[:, n_t + n_x:])) if n_g else -1
         self.desc.append([a, b, c])
 
     def jet_layer_bwd(self, lin, k0):
@@ -192,31 +215,70 @@ class _Packer:
         self.desc.append([a, b, -1])
 
 
-def pack_uni(model, variant):
+def _pack_uni(model, variant, src):
     cfg = model.config
     enc, emb = model.encoder.epic, model.embedder
     Et, Ed = cfg.encoder.dim_emb_time, cfg.encoder.dim_emb_discrete
     H, G = cfg.encoder.dim_hidden_local, cfg.encoder.dim_hidden_glob
     dev = next(model.parameters()).device
     pk = _Packer(dev)
+    L = src.lin
     pr = enc.epic_proj
-    pk.particle_layer(pr.mlp_local["0"], Et, Ed, 0, time_twice=True)
-    pk.particle_layer(pr.mlp_local["2"], 0, H, 0)
-    pk.jet_layer(pr.mlp_global["0"])
-    pk.jet_layer(pr.mlp_global["2"])
+    pk.particle_layer(L(pr.mlp_local["0"]), Et, Ed, 0, time_twice=True)
+    pk.particle_layer(L(pr.mlp_local["2"]), 0, H, 0)
+    pk.jet_layer(L(pr.mlp_global["0"]))
+    pk.jet_layer(L(pr.mlp_global["2"]))
     for i in range(enc.num_blocks):
         ly = enc.epic_layers[i]
-        pk.jet_layer(ly.fc_glob1)
-        pk.jet_layer(ly.fc_glob2)
-        pk.particle_layer(ly.fc_loc1, Et, H, G)
-        pk.particle_layer(ly.fc_loc2, 0, H, 0)
-    pk.particle_layer(enc.output_layer, Et, H, G)
-    off_table = pk.add(emb.discrete_embedding.table())
+        pk.jet_layer(L(ly.fc_glob1))
+        pk.jet_layer(L(ly.fc_glob2))
+        pk.particle_layer(L(ly.fc_loc1), Et, H, G)
+        pk.particle_layer(L(ly.fc_loc2), 0, H, 0)
+    pk.particle_layer(L(enc.output_layer), Et, H, G)
+    off_table = pk.add(src.tensor(emb.discrete_embedding.table, emb.discrete_embedding))
     packed = torch.cat(pk.chunks)
     desc = torch.tensor(pk.desc, dtype=torch.int32, device=dev).reshape(-1)
     return {"kind": "uni", "packed": packed, "desc": desc, "variant": variant, "num_blocks": enc.num_blocks,
+            "nb_branch": enc.num_blocks, "nb_fused_exec": 0,
             "use_skip": int(bool(cfg.encoder.skip_connection)), "off_table": off_table, "time_parts": pk.time_parts,
-            "mfma_flops_per_forward": sum(pk.mfma_flops)}
+            "time_lins": pk.time_lins, "second": pk.second, "mfma_flops_per_forward": sum(pk.mfma_flops)}
+
+
+def _pack_uni_bwd(model, src):
+    cfg = model.config
+    enc = model.encoder.epic
+    Et, Ed = cfg.encoder.dim_emb_time, cfg.encoder.dim_emb_discrete
+    H, G = cfg.encoder.dim_hidden_local, cfg.encoder.dim_hidden_glob
+    dev = next(model.parameters()).device
+    pk = _Packer(dev)
+    L = src.lin
+    pr = enc.epic_proj
+    pk.particle_layer_bwd(L(pr.mlp_local["0"]), Et, Ed, 0, time_twice=True)
+    pk.particle_layer_bwd(L(pr.mlp_local["2"]), 0, H, 0)
+    pk.jet_layer_bwd(L(pr.mlp_global["0"]), 2 * H)
+    pk.jet_layer_bwd(L(pr.mlp_global["2"]), H)
+    for i in range(enc.num_blocks):
+        ly = enc.epic_layers[i]
+        pk.jet_layer_bwd(L(ly.fc_glob1), 2 * H)
+        pk.jet_layer_bwd(L(ly.fc_glob2), H)
+        pk.particle_layer_bwd(L(ly.fc_loc1), Et, H, G)
+        pk.particle_layer_bwd(L(ly.fc_loc2), 0, H, 0)
+    pk.particle_layer_bwd(L(enc.output_layer), Et, H, G)
+    desc = torch.tensor(pk.desc, dtype=torch.int32, device=dev).reshape(-1)
+    return torch.cat(pk.chunks), desc, pk.second
+
+
+def _gather_maps(imap, second, n_flat):
+    """index map (1 + flat position, 0 = padding) -> (gather, gather2 | None); gather2 adds the time_twice blocks"""
+    idx = imap.long() - 1
+    gather = torch.where(idx < 0, torch.full_like(idx, n_flat), idx)           # padding -> the trailing zero
+    gather2 = None
+    if second:
+        gather2 = torch.full_like(idx, n_flat)
+        for off, ind in second:
+            i2 = ind.long() - 1
+            gather2[off:off + i2.numel()] = torch.where(i2 < 0, torch.full_like(i2, n_flat), i2)
+    return gather, gather2
 
 
 def pack_model(model):
@@ -224,26 +286,28 @@ def pack_model(model):
     is not one of the compiled width sets."""
     uv = eligible_uni(model)
     if uv is not None:
-        return pack_uni(model, uv)
-    variant = eligible(model)
-    if variant is None:
-        return None
-    pack = _pack_multi(model, variant, _RealSource())
+        variant, fwd, bwd = uv, _pack_uni, _pack_uni_bwd
+    else:
+        variant = eligible(model)
+        if variant is None:
+            return None
+        fwd = _pack_multi
+        bwd = lambda m, sb: _pack_multi_bwd(m, sb) + ([],)
+    pack = fwd(model, variant, _RealSource())
     src = _IndexSource(pack["packed"].device)
-    imap = _pack_multi(model, variant, src)["packed"]
+    im = fwd(model, variant, src)
+    imap = im["packed"]
     assert imap.numel() == pack["packed"].numel()
-    idx = imap.long() - 1
-    pack["gather"] = torch.where(idx < 0, torch.full_like(idx, src.n), idx)       # padding -> the trailing zero
+    pack["gather"], pack["gather2"] = _gather_maps(imap, im.get("second"), src.n)
     pack["getters"] = src.getters
     pack["items"], pack["n_flat"] = src.items, src.n
     pack["flat"] = None                                    # persistent [all sources | 0], see refresh_flat
     pack["zero"] = torch.zeros(1, dtype=torch.float32, device=imap.device)
     # backward weights (training): same sources, so the same flat buffer feeds a second gather
     srcb = _IndexSource(imap.device)
-    bmap, pack["desc_bwd"] = _pack_multi_bwd(model, srcb)
+    bmap, pack["desc_bwd"], second_b = bwd(model, srcb)
     assert srcb.n == src.n - _tail_sources(model)
-    idx = bmap.long() - 1
-    pack["gather_bwd"] = torch.where(idx < 0, torch.full_like(idx, src.n), idx)
+    pack["gather_bwd"], pack["gather2_bwd"] = _gather_maps(bmap, second_b, src.n)
     pack["packed_bwd"] = None                              # built on first training use
     pack["bwd_version"] = None
     return pack
@@ -252,8 +316,10 @@ def pack_model(model):
 def _tail_sources(model):
     """floats of the sources the forward pack appends after the layers (embedding parameters)"""
     emb = model.embedder
-    return (emb.continuous_embedding.weight.numel() + emb.continuous_embedding.bias.numel()
-            + emb.discrete_embedding.weight_v.numel())
+    n = emb.discrete_embedding.weight_v.numel()
+    if hasattr(emb, "continuous_embedding"):
+        n += emb.continuous_embedding.weight.numel() + emb.continuous_embedding.bias.numel()
+    return n
 
 
 def packed_bwd(pack, version):
@@ -264,6 +330,8 @@ def packed_bwd(pack, version):
             pack["packed_bwd"] = flat.index_select(0, pack["gather_bwd"])
         else:
             torch.index_select(flat, 0, pack["gather_bwd"], out=pack["packed_bwd"])
+        if pack["gather2_bwd"] is not None:
+            pack["packed_bwd"].add_(flat.index_select(0, pack["gather2_bwd"]))
         pack["bwd_version"] = version
     return pack["packed_bwd"]
 
@@ -380,7 +448,10 @@ def repack(pack, version):
     """Refresh the packed parameter buffer after an optimizer step (same architecture, new values)."""
     flat = refresh_flat(pack, version)
     torch.index_select(flat, 0, pack["gather"], out=pack["packed"])
-    pack["time_parts"] = [l.weight()[:, :n_t] for l, n_t in pack["time_lins"]]
+    if pack["gather2"] is not None:
+        pack["packed"].add_(flat.index_select(0, pack["gather2"]))
+    pack["time_parts"] = [(l.weight()[:, :n_t] + l.weight()[:, n_t:2 * n_t]) if twice else l.weight()[:, :n_t]
+                          for l, n_t, twice in pack["time_lins"]]
     return pack
 
 
@@ -475,9 +546,23 @@ def train_forward(pack, mi, x, k, temb, slots, n_slots, drop_p, seed, offset0, h
     return hc, hd
 
 
+def train_forward_uni(pack, mi, k, temb, slots, n_slots, drop_p, seed, offset0, hd):
+    """Training forward of the discrete-only model: logits -> hd (B*N,8), activations -> slots."""
+    call("mmb_fused_uni_train_forward", pack["variant"], mi.B, mi.N, f32(pack["packed"]), i32(pack["desc"]),
+         pack["num_blocks"], pack["use_skip"], pack["off_table"], f32(mi.maskf), i32(mi.counts), i64(k, "k"),
+         f32(temb, "temb"), temb.stride(0), C.c_void_p(slots.data_ptr()), n_slots, _fl(drop_p), seed, offset0, f32(hd),
+         stream())
+    return hd
+
+
 def train_backward(pack, pbwd, mi, slots, n_slots, drop_p, seed, offset0):
     """Reverse pass of the whole encoder for every jet in one launch (csrc/fused_epic_bwd.hip): fills the dZ / column-sum
     slots the weight-gradient kernel consumes.  slots: device int64 (n_slots, 3)."""
+    if pack["kind"] == "uni":
+        call("mmb_fused_uni_train_backward", pack["variant"], mi.B, mi.N, f32(pbwd), i32(pack["desc_bwd"]),
+             pack["num_blocks"], pack["use_skip"], f32(mi.maskf), i32(mi.counts), C.c_void_p(slots.data_ptr()), n_slots,
+             _fl(drop_p), seed, offset0, stream())
+        return
     call("mmb_fused_epic_train_backward", pack["variant"], mi.B, mi.N, f32(pbwd), i32(pack["desc_bwd"]), pack["nb_branch"],
          pack["nb_fused_exec"], pack["use_skip"], f32(mi.maskf), i32(mi.counts), C.c_void_p(slots.data_ptr()), n_slots,
          _fl(drop_p), seed, offset0, stream())

@@ -189,14 +189,15 @@ class MultiModalBridgeMatching(nn.Module):
         off = self._next_offset() if (self.training and self.config.encoder.dropout) else 0
         if self._tape is not None and self.use_fused_training:
             pack = self._fused_pack()
-            if pack is not None and pack["kind"] == "multi" and self._pack_serves(pack, state):
+            if pack is not None and self._pack_serves(pack, state):
                 from encoders import fused_train                        # taped forward in ONE launch
-                xs, ks = state.continuous.contiguous(), state.discrete.contiguous()
+                xs = state.continuous.contiguous() if pack["kind"] == "multi" else None
+                ks = state.discrete.contiguous()
                 if not self.use_fused_backward:                         # (layered reverse pass: per-step buffers)
                     return fused_train.forward(self, pack, loc, xs, ks, self._tape, self.seed, off)
                 ws = self._train_ws
-                if ws is None or ws.key != (mi.B, mi.N, str(xs.device)) or ws.pack is not pack:
-                    ws = self._train_ws = fused_train.Workspace(self, pack, mi.B, mi.N, xs.device)
+                if ws is None or ws.key != (mi.B, mi.N, str(ks.device)) or ws.pack is not pack:
+                    ws = self._train_ws = fused_train.Workspace(self, pack, mi.B, mi.N, ks.device)
                 return ws.forward(self, loc, xs, ks, self._tape, self.seed, off)
         return self.encoder(loc, glob, tape=self._tape, seed=self.seed, offset0=off)
 

@@ -252,6 +252,11 @@ def main():
             "kernel_time_ms": {k: round(v["ms"], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])},
         }
         if training is not None:
+            tr_step = (measured_traffic("training_step") or {}).get(args.workload)
+            if tr_step and B == 1024:                       # PMC passes were taken at 1024 jets per rank and step
+                per_rank = tr_step["bytes_per_step"]
+                training["hbm_traffic_bytes_per_rank_step"] = per_rank
+                training["hbm_frac"] = per_rank / (training["ms_per_step"] * 1e-3) / 8.0e12
             line["training"] = training
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, config, args.workload, args.cpu_jets, args.cpu_steps)

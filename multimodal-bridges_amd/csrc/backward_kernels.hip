@@ -382,8 +382,23 @@ grad_weight_rows_multi_kernel(const GwProb* __restrict__ probs, int n_probs) {
   const GwProb q = probs[i];
   if (id < q.block_begin || id >= q.block_end) return;
   const int local = (int)(id - q.block_begin);
-  const int bx = local % (int)q.nbx, rest = local / (int)q.nbx;
-  const int by = rest % (int)q.nby, bz = rest / (int)q.nby;
+  const int nbx = (int)q.nbx, nby = (int)q.nby;
+  int bx, by, bz;
+  if ((nbx & 7) == 0 && (q.block_begin & 7) == 0) {
+    // XCD-aware order: consecutive block ids go round-robin over the 8 XCDs, each with its own L2.  The nby
+    // blocks that stream the SAME rows of dZ (one per K window) are given ids 8 apart -- same XCD, dispatched
+    // together -- so the second reader finds the rows in that L2 instead of fetching them again.
+    const int xcd = local & 7, slot = local >> 3;
+    by = slot % nby;
+    const int t = slot / nby;
+    bx = (t % (nbx >> 3)) * 8 + xcd;
+    bz = t / (nbx >> 3);
+  } else {
+    bx = local % nbx;
+    const int rest = local / nbx;
+    by = rest % nby;
+    bz = rest / nby;
+  }
   grad_weight_rows_body<OT, KT>((int)q.M, q.X, q.x_ld, (int)q.K, q.dZ, q.dz_ld, (int)q.Nout, q.dW, q.dw_ld, q.db,
                                 (int)q.rpb, (int)q.replicas, q.rep_stride, q.db_stride, bx, by, bz);
 }

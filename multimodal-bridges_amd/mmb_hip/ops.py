@@ -447,7 +447,7 @@ def gw_record(X, dZ, dW, db, replicas, rep_stride, db_stride, block_begin):
     n = nbx * nby * nbz
     rec = [X.data_ptr(), dZ.data_ptr(), dW.data_ptr(), 0 if db is None else db.data_ptr(), X.stride(0), dZ.stride(0),
            dW.stride(0), rep_stride, db_stride, M, K, Nout, rpb, replicas, nbx, nby, block_begin, block_begin + n]
-    return rec, n
+    return rec, (n + 7) // 8 * 8          # ranges start on multiples of 8 (XCD-aware block order); gap blocks idle
 
 
 def grad_weight_rows_multi(cls, table, n_probs, total_blocks):

@@ -94,6 +94,26 @@ struct SaveSlot {
 struct NoTrain {
   static constexpr bool on = false;
 };
+
+// Keep-bits of the inverted dropout for the HT*16 values a lane holds of a (rows, 32*HT) activation: bit
+// 16 t + r belongs to register r of tile t.  Same Philox stream and indexing as mmb_linear_cat's epilogue
+// (element (row, col) -> counter (row*H + col) >> 2, word col & 3): a lane's registers 4q..4q+3 are four
+// consecutive columns, i.e. ONE counter.  Deliberately a rolled loop: unrolled, the HT*4 Philox states are
+// all live at once and push the MFMA loops around it into scratch.
+template <int HT>
+__device__ __forceinline__ uint64_t dropout_keep_bits(float p, uint64_t seed, uint64_t off, uint64_t row, int half) {
+  uint64_t bits = 0;
+#pragma unroll 1
+  for (int tq = 0; tq < HT * 4; ++tq) {
+    const uint64_t idx = row * (32 * HT) + (uint64_t)(32 * (tq >> 2) + 8 * (tq & 3) + 4 * half);
+    uint32_t rr[4];
+    philox4(seed, off, idx >> 2, 0xD0D0u, rr);
+    const uint32_t nib = (u01(rr[0]) < p ? 0u : 1u) | (u01(rr[1]) < p ? 0u : 2u) | (u01(rr[2]) < p ? 0u : 4u) |
+                         (u01(rr[3]) < p ? 0u : 8u);
+    bits |= (uint64_t)nib << (4 * tq);
+  }
+  return bits;
+}
 struct Train {
   static constexpr bool on = true;
   const SaveSlot* tab;

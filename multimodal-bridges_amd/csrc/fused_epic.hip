@@ -131,15 +131,16 @@ struct Epic {
       dr = tr.drop_p > 0.0f;
       if (dr) ++tr.off;
     }
+    uint64_t keep = 0;
+    if constexpr (TR::on) {
+      if (dr) keep = dropout_keep_bits<HT>(tr.drop_p, tr.seed, tr.off, (uint64_t)tr.b * tr.N + tr.p, half);
+    }
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
       ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; x[t][r] = lrelu_f(x[t][r]); });
       if constexpr (TR::on) {
         if (dr) {
-          ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
-            const uint64_t idx = ((uint64_t)tr.b * tr.N + tr.p) * H + (32 * t + 8 * q + 4 * half);
-            uint32_t rr[4];
-            philox4(tr.seed, tr.off, idx >> 2, 0xD0D0u, rr);
-            ffor<4>([&](auto ec) { constexpr int e = decltype(ec)::v; x[t][4 * q + e] = tr.drop(x[t][4 * q + e], rr[e]); }); });
+          ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v;
+            x[t][r] = ((keep >> (16 * t + r)) & 1) ? x[t][r] / (1.0f - tr.drop_p) : 0.0f; });
         }
       }
       if (use_skip) {

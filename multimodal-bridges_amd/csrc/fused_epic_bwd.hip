@@ -131,6 +131,8 @@ struct EpicB {
     Rows r_skip = r_out;
     if (use_skip) r_skip = sl.rows();
     const Rows r_dz2 = sl.rows();
+    uint64_t keep = 0;
+    if (dr) keep = dropout_keep_bits<HT>(drop_p, seed, off_l, (uint64_t)sl.b * sl.N + sl.p, half);
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
       if (use_skip) {
         f32x16 sk = fetch_tile(S, t, tid);
@@ -142,16 +144,10 @@ struct EpicB {
         const f32x16 k = load_tile(r_skip, t);
         ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; a[r] -= k[r]; });
       }
-      ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
-        uint32_t rr[4] = {0u, 0u, 0u, 0u};
-        if (dr) {
-          const uint64_t idx = ((uint64_t)sl.b * sl.N + sl.p) * H + (32 * t + 8 * q + 4 * half);
-          philox4(seed, off_l, idx >> 2, 0xD0D0u, rr);
-        }
-        ffor<4>([&](auto ec) { constexpr int e = decltype(ec)::v;
-          float g = dx[t][4 * q + e];
-          if (dr) g = drop_grad(g, rr[e], drop_p);
-          dx[t][4 * q + e] = g * lrelu_grad(a[4 * q + e]); }); });
+      ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v;
+        float g = dx[t][r];
+        if (dr) g = ((keep >> (16 * t + r)) & 1) ? g / (1.0f - drop_p) : 0.0f;
+        dx[t][r] = g * lrelu_grad(a[r]); });
       store_tile(r_dz2, t, dx[t]); });
     // ---- d lh = W2^T d y1 ; lh = lrelu(z1)
     f32x16 dlh[HT];

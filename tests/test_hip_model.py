@@ -388,3 +388,43 @@ def test_fused_repack_tracks_parameter_updates(golden, name):
     assert torch.equal(p1["packed"], fresh["packed"])
     for a, b in zip(p1["time_parts"], fresh["time_parts"]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name,blocks,skip", [("mm_mid", [1, 1, 2], False), ("mm_mid", [3, 3, 1], True),
+                                              ("uni_mid", 1, False), ("uni_mid", 3, True)])
+def test_fused_training_other_depths(golden, name, blocks, skip):
+    """Fused training step against the layered one on freshly initialised models of other depths and without the
+    skip connection (the slot tables of both kernels change with either)."""
+    from pipeline.configs import ExperimentConfigs
+    from model.multimodal_bridge_matching import MultiModalBridgeMatching
+    from tensorclass import TensorMultiModal
+    g = golden(name)
+    cfg = copy.deepcopy(g.cfg)
+    cfg["data"]["target_path"] = GOLDEN
+    cfg["encoder"]["num_blocks"] = blocks
+    cfg["encoder"]["skip_connection"] = skip
+    cfg["encoder"]["dropout"] = 0.1
+    torch.manual_seed(17)
+    model = MultiModalBridgeMatching(ExperimentConfigs(cfg)).cuda().train()
+    t = g.t
+    c = lambda a: None if a is None else a.cuda()
+    res = {}
+    for fused in (True, False):
+        model.use_fused_training = model.use_fused_backward = fused
+        model.manual_seed(3)
+        state = TensorMultiModal(c(t["time"]), c(t.get("xt")), c(t["kt"]), c(t["mask"]))
+        out = model.step_from_state(state, batch_of(g), "train", True)
+        model.zero_grad(set_to_none=True)
+        out["loss"].backward()
+        res[fused] = (out["loss"].detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()
+                                                     if p.grad is not None})
+    assert model._train_ws is not None, "the fused training step did not run"
+    close(res[True][0], res[False][0], rtol=1e-5, atol=1e-6)
+    gf, gl = res[True][1], res[False][1]
+    assert gf.keys() == gl.keys(), set(gf) ^ set(gl)
+    for n in gf:
+        scale = float(gl[n].abs().max()) + 1e-12
+        try:
+            close(gf[n], gl[n], rtol=2e-3, atol=2e-4 * scale + 1e-7)
+        except AssertionError as e:
+            raise AssertionError(f"gradient of {n}: {e}") from None

@@ -109,6 +109,13 @@ int mmb_telegraph_probs(int B, int N, int V, const float* t, const int64_t* k0, 
 int mmb_bridge_drift(int B, int N, int Dc, const float* t, const float* xt, const float* x0,
                      const float* x1, int bridge_kind, float* out, void* stream);
 
+/* Jet-level observables of a post-processed sample on device (evaluation; datamodules/utils.py:437-475 JetFeatures with
+ * the kinematics of ParticleClouds :21-42, the flavour counts of :558-574 and the jet charge of :548-556).
+ * x (B,N,Dc>=3) = (pt, eta_rel, phi_rel, ...) | NULL, k (B,N) tokens | NULL, maskf (B,N).
+ * out (B,19): numParticles, px, py, pz, e, pt, m, eta, phi, 8 flavour counts, charge, jet charge (kappa = 1). */
+int mmb_jet_observables(int B, int N, int Dc, const float* x, const int64_t* k, const float* maskf, float* out,
+                        void* stream);
+
 /* Generation post-processing, in place (pipeline/callbacks_generator.py:99-128 + TensorMultiModal.apply_mask,
  * tensorclass.py:96-106): x = x*scale[d] + shift[d] (scale/shift of length Dc, both NULL for no transform:
  * "standardize" -> std/mean, "normalize" -> (max-min)/min), log_pt != 0 additionally x[...,0] = exp(x[...,0]) - 1e-6;

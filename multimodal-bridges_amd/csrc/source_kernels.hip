@@ -77,6 +77,60 @@ source_uniform_kernel(int N, int Dc, int V, int sample_masks, const float* __res
   if (counts && lane == 0) counts[b] = n_on;
 }
 
+// ---- jet-level observables of a (post-processed) sample: datamodules/utils.py:437-475 (JetFeatures),
+// :21-42 (ParticleClouds kinematics), :558-574 (flavour counts), :548-556 (jet charge).  One wave per jet:
+// lanes stride over the N slots, wavefront reduction, lane 0 finishes the jet four-vector.
+// out (B, 19): numParticles, px, py, pz, e, pt, m, eta, phi, counts[0..7] (tokens of REAL particles),
+// charge (kappa=0), jet charge (kappa=1).  As upstream, the kinematic sums run over ALL slots (a
+// post-processed sample has zeros in the padded ones) and only the flavour counts look at the mask.
+__global__ void __launch_bounds__(256)
+jet_observables_kernel(int B, int N, int Dc, const float* __restrict__ x, const int64_t* __restrict__ k,
+                       const float* __restrict__ maskf, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;         // n, px, py, pz, e, cnt[8], q, q*pt
+  for (int n = lane; n < N; n += 64) {
+    const int64_t p = (int64_t)b * N + n;
+    const float m = maskf[p];
+    acc[0] += m;
+    float pt = 0.0f;
+    if (x != nullptr) {
+      pt = x[p * Dc];
+      const float eta = x[p * Dc + 1], phi = x[p * Dc + 2];
+      acc[1] += pt * cosf(phi);
+      acc[2] += pt * sinf(phi);
+      acc[3] += pt * sinhf(eta);
+      acc[4] += pt * coshf(eta);
+    }
+    if (k != nullptr) {
+      const int tok = (int)k[p];
+      if (m > 0.0f && tok >= 0 && tok < 8) acc[5 + tok] += 1.0f;
+      const float q = (tok >= 2 && tok < 8) ? ((tok & 1) ? 1.0f : -1.0f) : 0.0f;    // map_tokens_to_basis(...)[..., -1]
+      acc[13] += q;
+      acc[14] += q * pt;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 15; ++i) acc[i] = wave_sum(acc[i]);
+  if (lane == 0) {
+    float* o = out + (int64_t)b * 19;
+    const float px = acc[1], py = acc[2], pz = acc[3], e = acc[4];
+    const float pt = sqrtf(px * px + py * py);
+    o[0] = acc[0]; o[1] = px; o[2] = py; o[3] = pz; o[4] = e;
+    o[5] = pt;
+    o[6] = sqrtf(e * e - pt * pt - pz * pz);
+    o[7] = 0.5f * logf((pt + pz) / (pt - pz));
+    o[8] = atan2f(py, px);
+#pragma unroll
+    for (int v = 0; v < 8; ++v) o[9 + v] = acc[5 + v];
+    o[17] = acc[13];
+    o[18] = acc[14] / pt;
+  }
+}
+
 }  // namespace mmb
 
 using namespace mmb;
@@ -95,4 +149,14 @@ extern "C" int mmb_source_uniform(int B, int N, int Dc, int V, int sample_masks,
   hipLaunchKernelGGL(source_uniform_kernel, dim3(B), dim3(64), 0, as_stream(stream), N, Dc, V, sample_masks, pmf,
                      n_pmf, seed, offset, x0, k0, mask_i64, maskf, counts);
   return check_launch("mmb_source_uniform");
+}
+
+extern "C" int mmb_jet_observables(int B, int N, int Dc, const float* x, const int64_t* k, const float* maskf,
+                                   float* out, void* stream) {
+  MMB_REQUIRE(B > 0 && N > 0, "mmb_jet_observables: empty batch");
+  MMB_REQUIRE(maskf && out && (x || k), "mmb_jet_observables: NULL argument");
+  if (x) MMB_REQUIRE(Dc >= 3, "mmb_jet_observables: needs (pt, eta_rel, phi_rel), got Dc=%d", Dc);
+  hipLaunchKernelGGL(jet_observables_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(stream), B, N, Dc, x, k, maskf,
+                     out);
+  return check_launch("mmb_jet_observables");
 }

@@ -460,3 +460,30 @@ def weight_norm_multi(table, n_rows):
 
 def weight_norm_bwd_multi(table, n_rows):
     call("mmb_weight_norm_bwd_multi", n_rows, C.c_void_p(table.data_ptr()), stream())
+
+
+OBSERVABLES = ("numParticles", "px", "py", "pz", "e", "pt", "m", "eta", "phi", "numPhotons", "numNeutralHadrons",
+               "numNegativeHadrons", "numPositiveHadrons", "numElectrons", "numPositrons", "numMuons", "numAntiMuons",
+               "charge", "jet_charge")
+
+
+def jet_observables(x, k, mask):
+    """(B,19) jet-level observables (columns: OBSERVABLES) of a post-processed sample, one wave per jet."""
+    B, N = mask.shape[0], mask.shape[1]
+    maskf = mask.reshape(B, N).float().contiguous()
+    out = torch.empty(B, 19, dtype=torch.float32, device=maskf.device)
+    Dc = x.shape[-1] if x is not None else 0
+    call("mmb_jet_observables", B, N, Dc, f32(None if x is None else x.contiguous(), "x"),
+         i64(None if k is None else k.contiguous(), "k"), f32(maskf, "maskf"), f32(out), stream())
+    return out
+
+
+def wasserstein_1d(a, b):
+    """scipy.stats.wasserstein_distance for two equally weighted 1-D samples, on device (utils.py:531-534):
+    the integral of |F_a - F_b| over the merged support."""
+    a, b = a.reshape(-1).double().sort().values, b.reshape(-1).double().sort().values
+    allv = torch.cat([a, b]).sort().values
+    deltas = allv[1:] - allv[:-1]
+    ca = torch.searchsorted(a, allv[:-1], right=True).double() / a.numel()
+    cb = torch.searchsorted(b, allv[:-1], right=True).double() / b.numel()
+    return ((ca - cb).abs() * deltas).sum()

@@ -451,3 +451,29 @@ def test_weight_norm_multi_and_backward(ops):
         close(dv, gv, rtol=1e-4, atol=1e-5)
         close(dg, ggr.reshape(-1), rtol=1e-4, atol=1e-5)
         close(db, dbr.sum(0), rtol=1e-5, atol=1e-5)
+
+
+def test_jet_observables_and_w1(ops):
+    """Device jet observables (one wave per jet) against the CPU restatement of JetFeatures, and the device
+    Wasserstein-1 against scipy."""
+    import scipy.stats
+    from oracle.observables import jet_observables as ref_obs
+    g = torch.Generator().manual_seed(8)
+    B, N = 203, 128
+    mask = (torch.rand(B, N, 1, generator=g) < 0.4).long()
+    x = torch.randn(B, N, 3, generator=g) * torch.tensor([0.5, 0.3, 0.3])
+    x[..., 0] = x[..., 0].abs() + 0.01
+    x = x * mask                                          # a post-processed sample: zeros in the padded slots
+    k = torch.randint(0, 8, (B, N, 1), generator=g) * mask
+    want = ref_obs(x, k, mask)
+    got = ops.jet_observables(dev(x), dev(k), dev(mask)).cpu()
+    for i, name in enumerate(ops.OBSERVABLES):
+        close(got[:, i], want[name], rtol=2e-4, atol=2e-5)
+    # discrete-only sample
+    got_d = ops.jet_observables(None, dev(k), dev(mask)).cpu()
+    for i, name in enumerate(ops.OBSERVABLES):
+        if name.startswith("num") or name == "charge":
+            close(got_d[:, i], want[name], rtol=0, atol=0)
+    a, b = torch.randn(1000, generator=g), torch.randn(777, generator=g) * 1.3 + 0.2
+    w = float(ops.wasserstein_1d(dev(a), dev(b)))
+    assert abs(w - scipy.stats.wasserstein_distance(a.numpy(), b.numpy())) < 1e-6

@@ -37,3 +37,22 @@ def test_train_resume_generate(golden, tmp_path):
     assert gen.continuous.shape == (n_test, 16, 3) and gen.discrete.shape == (n_test, 16, 1)
     assert int(gen.discrete.min()) >= 0 and int(gen.discrete.max()) < 8
     assert torch.isfinite(gen.continuous).all()
+
+
+def test_evaluate_report_on_device():
+    """pipeline.evaluate: device observables + W1 of two synthetic post-processed samples; identical samples -> 0."""
+    import torch
+    from tensorclass import TensorMultiModal
+    from pipeline.evaluate import wasserstein_report
+    g = torch.Generator().manual_seed(1)
+    def sample(shift):
+        mask = (torch.rand(300, 64, 1, generator=g) < 0.5).long()
+        x = (torch.randn(300, 64, 3, generator=g) * 0.3 + shift).abs() * mask
+        k = torch.randint(0, 8, (300, 64, 1), generator=g) * mask
+        return TensorMultiModal(None, x.cuda(), k.cuda(), mask.cuda())
+    a, b = sample(0.0), sample(0.2)
+    rep = wasserstein_report(a, b)
+    assert set(rep) >= {"pt", "m", "numParticles", "numPhotons", "charge", "jet_charge"}
+    assert all(v >= 0.0 for v in rep.values()) and rep["pt"] > 0.0
+    same = wasserstein_report(a, a, features=["pt", "numParticles"])
+    assert same == {"pt": 0.0, "numParticles": 0.0}

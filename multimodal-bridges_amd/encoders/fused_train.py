@@ -369,6 +369,7 @@ class Workspace:
         self.pack = pack
         self.grad_ptrs = None
         self.own_grads = None
+        self.own_views = {}
         self.inv_base = None
 
     # ---- weight-norm backward table: rebuilt whenever a parameter's .grad buffer or storage moved
@@ -379,6 +380,10 @@ class Workspace:
             yield layer.bias
 
     def _wn_table(self, model):
+        own = self.own_views
+        for p in self._params():                           # zero_grad(set_to_none=True) loops: hand the buffers back
+            if p.grad is None and id(p) in own:
+                p.grad = own[id(p)]
         ptrs = tuple((p.data_ptr(), -1 if p.grad is None else p.grad.data_ptr()) for p in self._params())
         if ptrs == self.grad_ptrs:
             return
@@ -387,7 +392,7 @@ class Workspace:
             flat = torch.zeros(sum(p.numel() for p in missing), dtype=torch.float32, device=self.arena.device)
             o = 0
             for p in missing:
-                p.grad = flat[o:o + p.numel()].view_as(p)
+                p.grad = own[id(p)] = flat[o:o + p.numel()].view_as(p)
                 o += p.numel()
             self.own_grads = flat
         ar = lambda n: torch.arange(n, dtype=torch.int64)

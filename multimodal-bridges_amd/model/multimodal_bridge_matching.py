@@ -195,9 +195,16 @@ class MultiModalBridgeMatching(nn.Module):
                 ks = state.discrete.contiguous()
                 if not self.use_fused_backward:                         # (layered reverse pass: per-step buffers)
                     return fused_train.forward(self, pack, loc, xs, ks, self._tape, self.seed, off)
-                ws = self._train_ws
-                if ws is None or ws.key != (mi.B, mi.N, str(ks.device)) or ws.pack is not pack:
-                    ws = self._train_ws = fused_train.Workspace(self, pack, mi.B, mi.N, ks.device)
+                key = (mi.B, mi.N, str(ks.device))
+                cache = self._train_ws if isinstance(self._train_ws, dict) else {}
+                ws = cache.get(key)
+                if ws is None or ws.pack is not pack:
+                    ws = fused_train.Workspace(self, pack, mi.B, mi.N, ks.device)
+                    cache = {k_: v for k_, v in list(cache.items())[-1:] if v.pack is pack}   # keep one other shape
+                    cache[key] = ws                                                           # (the epoch's last batch)
+                else:
+                    cache[key] = cache.pop(key)                                               # most recent last
+                self._train_ws = cache
                 return ws.forward(self, loc, xs, ks, self._tape, self.seed, off)
         return self.encoder(loc, glob, tape=self._tape, seed=self.seed, offset0=off)
 

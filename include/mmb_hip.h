@@ -322,8 +322,9 @@ int mmb_fused_epic_forward(int variant, int B, int N, const float* packed, const
  * offsets offset0+1, +2, ... in execution order) and every activation the reverse pass reads, written row-major
  * from the accumulator registers.  slots: device array of n_slots records {float* p; int64 ld; int64 n}
  * (destination, row pitch, floats available from p) in execution order: per branch [projection: local.0 pre/out,
- * local.2 pre/out, pooled, global.0 pre/out, global.2 pre/out; per layer: pooled, fc_glob1 out, g', g_out, fc_loc1
- * out, l_out; output], the concatenated global vector, fused encoder [layers; output], heads [.0 pre/out] x 2.
+ * local.2 pre/out, pooled, global.0 pre/out, global.2 pre/out; per layer: pooled, fc_glob1 out, g', g_out, sign words
+ * of fc_loc1, fc_loc1 out, sign words of l_out, l_out (sign words: 256 x 64-bit per jet: bit 16t+r of thread i = sign of the leaky-relu
+ * input behind register r of tile t); output], the concatenated global vector, fused encoder [layers; output], heads [.0 pre/out] x 2.
  * head_c (B*N,3), head_d (B*N,8). */
 int mmb_fused_epic_train_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
                                  int nb_branch, int nb_fused_exec, int use_skip,
@@ -340,7 +341,8 @@ int mmb_fused_epic_train_forward(int variant, int B, int N, const float* packed,
  * packed_bwd/desc_bwd: mmb_hip.fused.packed_bwd (transposed x-parts in fragment order).  slots: records as above:
  * [0] d f (rows,2Hb) [1] d h from the heads (rows,2Hb) [2] d cat[h1,h2] (rows,2Hb) [3] d temb (B,Et), then per head
  * {d head, .0 pre, .0 dZ, column sums}, fused encoder {column sums of the output layer; per layer, last first:
- * l_out, [skip], fc_loc2 dZ, fc_loc1 out, fc_loc1 dZ, its column sums, g', fc_glob2 dZ, fc_glob1 out, fc_glob1 dZ},
+ * sign words of l_out, fc_loc2 dZ, sign words of fc_loc1, fc_loc1 dZ, its column sums, g', fc_glob2 dZ, fc_glob1 out,
+ * fc_glob1 dZ},
  * per branch the same followed by the projection {global.2 pre, dZ, global.0 pre, dZ, local.2 pre, dZ, local.0 pre,
  * dZ, column sums} and, for the continuous branch, d (continuous embedding) (rows,Ec). */
 int mmb_fused_epic_train_backward(int variant, int B, int N, const float* packed_bwd, const int32_t* desc_bwd,
@@ -350,7 +352,7 @@ int mmb_fused_epic_train_backward(int variant, int B, int N, const float* packed
                                   void* stream);
 
 /* The same pair for the discrete-only UniModalEPiC (multimodal_epic.py:44-64; one EPiC encoder with projection on
- * cat[t, t, k_emb] whose output layer emits the V logits).  Forward slots: projection 9, layers 6 each.  Backward
+ * cat[t, t, k_emb] whose output layer emits the V logits).  Forward slots: projection 9, layers 8 each.  Backward
  * slots: [0] d temb (B,Et), d logits (rows,8), column sums of the output layer (B,8), layers last..first, projection. */
 int mmb_fused_uni_train_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
                                 int num_blocks, int use_skip, int off_table,

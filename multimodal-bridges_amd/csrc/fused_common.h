@@ -144,6 +144,13 @@ struct Train {
         const float4 v = make_float4(x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), R, vo, (32 * t + 8 * q) * 4, 0); }); });
   }
+  // one 64-bit word per thread (sign bits of the HT*16 values a lane holds) -> word b*256 + tid of the slot;
+  // only the reverse kernel reads it, with the same thread mapping
+  __device__ __forceinline__ void bits(uint64_t v, int tid) {
+    const SaveSlot s = next();
+    const int64_t i = (int64_t)b * FE_THREADS + tid;
+    if (2 * (i + 1) <= s.n) reinterpret_cast<uint64_t*>(s.p)[i] = v;
+  }
   // W floats of a per-jet vector (LDS) -> row b of the slot
   __device__ __forceinline__ void vec(const float* v, int W, int tid) {
     const SaveSlot s = next();
@@ -209,7 +216,23 @@ struct Slots {
     return i + W <= s.n ? s.p + i : nullptr;
   }
   __device__ __forceinline__ float* row(int W) { return row_of(next(), W); }
+  __device__ __forceinline__ uint64_t bits(int tid) {
+    const SaveSlot s = next();
+    const int64_t i = (int64_t)b * FE_THREADS + tid;
+    return 2 * (i + 1) <= s.n ? reinterpret_cast<const uint64_t*>(s.p)[i] : 0ull;
+  }
 };
+
+// bit 16 t + r = (x[t][r] > 0): what the reverse pass needs of a leaky-relu input (built from 32-bit words:
+// 64-bit shifts are multi-instruction on the VALU)
+template <int HT>
+__device__ __forceinline__ uint64_t sign_bits(const f32x16 (&x)[HT]) {
+  uint32_t w[2] = {0u, 0u};
+  ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+    ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v;
+      w[t >> 1] |= (x[t][r] > 0.0f ? 1u : 0u) << (16 * (t & 1) + r); }); });
+  return (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+}
 
 // Per-jet matvec  out[o] = act( sum_k WT[k*O+o] v(k) + bias[o] ) + add[o]  with ONE barrier.
 // The O outputs are split over the 4 waves (OW each); inside a wave lane = part*G + og: og picks VW

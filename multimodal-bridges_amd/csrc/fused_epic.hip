@@ -64,7 +64,9 @@ struct Epic {
   }
 
   // EPiCLayer (epic.py:187-208) + the encoder-level skip add (:89-90).  skipf(IF<t>) yields skip tile t.
-  // Training slots: pooled, gh, g_new, g_out, lh, l_out.
+  // Training slots: pooled, gh, g_new, g_out, sign bits of lh's pre-activation, lh, sign bits of y1 (the
+  // leaky-relu input behind l_out), l_out: the reverse pass takes the two derivatives from 2 x 8 bytes per lane instead of
+  // re-reading lh, l_out and the skip tensor.
   template <typename SkipFn, class TR>
   static __device__ __forceinline__ void layer(f32x16 (&x)[HT], SkipFn&& skipf, bool use_skip,
                                                const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
@@ -115,6 +117,7 @@ struct Epic {
     acc_init<HT>(lh, m, cv, L.dvec, half);
     if constexpr (HT <= 2) mma_prefetch(pre2, R, l2.wx, lane);   // arrives under the first GEMM
     mma_x<HT, HT>(lh, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, R, l1.wx, lane, pre1);
+    if constexpr (TR::on) tr.bits(sign_bits<HT>(lh), tid);
     act_tiles<HT, MMB_ACT_LRELU>(lh);
     if constexpr (TR::on) tr.template tiles<HT>(lh, half);
     if constexpr (HT > 2) mma_prefetch(pre2, R, l2.wx, lane);
@@ -133,14 +136,16 @@ struct Epic {
     }
     uint64_t keep = 0;
     if constexpr (TR::on) {
+      tr.bits(sign_bits<HT>(x), tid);
       if (dr) keep = dropout_keep_bits<HT>(tr.drop_p, tr.seed, tr.off, (uint64_t)tr.b * tr.N + tr.p, half);
     }
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
       ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; x[t][r] = lrelu_f(x[t][r]); });
       if constexpr (TR::on) {
         if (dr) {
+          const uint32_t kw = (uint32_t)(keep >> (32 * (t >> 1)));
           ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v;
-            x[t][r] = ((keep >> (16 * t + r)) & 1) ? x[t][r] / (1.0f - tr.drop_p) : 0.0f; });
+            x[t][r] = ((kw >> (16 * (t & 1) + r)) & 1u) ? x[t][r] / (1.0f - tr.drop_p) : 0.0f; });
         }
       }
       if (use_skip) {
@@ -264,8 +269,8 @@ __device__ __forceinline__ void embed_tiles(f32x16& tc, f32x16& td, const float 
 
 // Whole MultiModalEPiC forward for this jet.  which: 0 continuous head, 1 discrete head, 2 both.
 // hc: tile whose features 0..DC-1 are the drift; hd: tile whose features 0..V-1 are the logits.
-// Training (TR = Train): slots in execution order -- per branch [projection 9, layers 6 each, output 1],
-// the concatenated global vector 1, fused encoder [layers 6 each, output 1], heads [pre, hidden] x 2.
+// Training (TR = Train): slots in execution order -- per branch [projection 9, layers 8 each, output 1],
+// the concatenated global vector 1, fused encoder [layers 8 each, output 1], heads [pre, hidden] x 2.
 template <class DM, class TR>
 __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* S, const float (&xp)[4], int kp, float m,
                                             int which, f32x16& hc, f32x16& hd, int tid, TR& tr) {
@@ -618,7 +623,7 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
 // epic.py:155 -- both column blocks are summed into one time vector on the host), whose output
 // layer emits the V logits directly (no heads).
 
-// Training (TR = Train) slots: projection 9, layers 6 each (the V logits of the output layer go to the caller).
+// Training (TR = Train) slots: projection 9, layers 8 each (the V logits of the output layer go to the caller).
 template <class DM, class TR>
 __device__ __forceinline__ void forward_uni(const FusedArgs& A, Lds& L, float4* S, const float* tab, int kp, float m,
                                             f32x16& hd, int tid, TR& nt) {
@@ -819,7 +824,7 @@ extern "C" int mmb_fused_epic_train_forward(int variant, int B, int N, const flo
   MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_epic_train_forward: unknown variant %d", variant);
   MMB_REQUIRE(x && k && temb && head_c && head_d && slots, "mmb_fused_epic_train_forward: NULL argument");
   MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_fused_epic_train_forward: dropout p=%f outside [0,1)", drop_p);
-  const int expect = 2 * (10 + 6 * nb_branch) + 1 + 6 * nb_fused_exec + 1 + 4;
+  const int expect = 2 * (10 + 8 * nb_branch) + 1 + 8 * nb_fused_exec + 1 + 4;
   MMB_REQUIRE(n_slots == expect, "mmb_fused_epic_train_forward: %d save slots given, the architecture has %d", n_slots,
               expect);
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
@@ -866,7 +871,7 @@ extern "C" int mmb_fused_uni_train_forward(int variant, int B, int N, const floa
   MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_uni_train_forward: unknown variant %d", variant);
   MMB_REQUIRE(k && temb && head_d && slots, "mmb_fused_uni_train_forward: NULL argument");
   MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_fused_uni_train_forward: dropout p=%f outside [0,1)", drop_p);
-  const int expect = 9 + 6 * num_blocks;
+  const int expect = 9 + 8 * num_blocks;
   MMB_REQUIRE(n_slots == expect, "mmb_fused_uni_train_forward: %d save slots given, the architecture has %d", n_slots,
               expect);
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), num_blocks, 0, use_skip, 0, 0, off_table, B, N,

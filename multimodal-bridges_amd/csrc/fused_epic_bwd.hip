@@ -119,7 +119,7 @@ struct EpicB {
 
   // EPiCLayer + encoder-level skip.  In: dx = d l_out, LB.dg = d g_out.  Out: dx = d x_local, LB.dg = d x_global;
   // the skip gradients accumulate in S (tiles) and LB.dgskip.
-  // Slots: l_out, [skip], dz_l2, lh, dz_l1, S_l1, g_new, dz_g2, gh, dz_g1.
+  // Slots: sign bits of y1, dz_l2, sign bits of lh's pre-activation, dz_l1, S_l1, g_new, dz_g2, gh, dz_g1.
   static __device__ __forceinline__ void layer_bwd(f32x16 (&dx)[HT], const BDesc* __restrict__ D, const float* __restrict__ P,
                                                    bool use_skip, LdsB& LB, float4* S, Slots& sl, float m, int tid,
                                                    float drop_p, uint64_t seed, uint64_t off_g, uint64_t off_l) {
@@ -127,9 +127,7 @@ struct EpicB {
     const BDesc g1 = D[0], g2 = D[1], l1 = D[2], l2 = D[3];
     const bool dr = drop_p > 0.0f;
     // ---- l_out = drop(lrelu(y1)) + skip ;  y1 = x + W2 lh + b2
-    const Rows r_out = sl.rows();
-    Rows r_skip = r_out;
-    if (use_skip) r_skip = sl.rows();
+    const uint64_t sgn_y1 = sl.bits(tid);
     const Rows r_dz2 = sl.rows();
     uint64_t keep = 0;
     if (dr) keep = dropout_keep_bits<HT>(drop_p, seed, off_l, (uint64_t)sl.b * sl.N + sl.p, half);
@@ -139,24 +137,23 @@ struct EpicB {
         ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; sk[r] += dx[t][r]; });
         park_tile(S, t, sk, tid);
       }
-      f32x16 a = load_tile(r_out, t);
-      if (use_skip) {
-        const f32x16 k = load_tile(r_skip, t);
-        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; a[r] -= k[r]; });
-      }
+      const uint32_t kw = (uint32_t)(keep >> (32 * (t >> 1))), sw = (uint32_t)(sgn_y1 >> (32 * (t >> 1)));
       ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v;
+        constexpr int bit = 16 * (t & 1) + r;
         float g = dx[t][r];
-        if (dr) g = ((keep >> (16 * t + r)) & 1) ? g / (1.0f - drop_p) : 0.0f;
-        dx[t][r] = g * lrelu_grad(a[r]); });
+        if (dr) g = ((kw >> bit) & 1u) ? g / (1.0f - drop_p) : 0.0f;
+        dx[t][r] = ((sw >> bit) & 1u) ? g : 0.01f * g; });
       store_tile(r_dz2, t, dx[t]); });
     // ---- d lh = W2^T d y1 ; lh = lrelu(z1)
     f32x16 dlh[HT];
     zero_tiles<HT>(dlh);
     mma_go<HT, HT>(dlh, [&](auto fc) -> const f32x16& { return dx[decltype(fc)::v]; }, P, l2.a, lane);
-    const Rows r_lh = sl.rows(), r_dz1 = sl.rows();
+    const uint64_t sgn_lh = sl.bits(tid);
+    const Rows r_dz1 = sl.rows();
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
-      const f32x16 a = load_tile(r_lh, t);
-      ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; dlh[t][r] *= lrelu_grad(a[r]); });
+      const uint32_t sw = (uint32_t)(sgn_lh >> (32 * (t >> 1)));
+      ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v;
+        if (!((sw >> (16 * (t & 1) + r)) & 1u)) dlh[t][r] *= 0.01f; });
       store_tile(r_dz1, t, dlh[t]); });
     colsum<HT>(dlh, LB, sl, tid);
     // d x = d y1 (residual) + Wx1^T d z1
@@ -452,7 +449,7 @@ extern "C" int mmb_fused_uni_train_backward(int variant, int B, int N, const flo
   MMB_REQUIRE(packed_bwd && desc_bwd && maskf && counts && slots, "mmb_fused_uni_train_backward: NULL argument");
   MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_uni_train_backward: unknown variant %d", variant);
   MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_fused_uni_train_backward: dropout p=%f outside [0,1)", drop_p);
-  const int expect = 1 + 2 + num_blocks * (use_skip ? 10 : 9) + 9;
+  const int expect = 1 + 2 + num_blocks * 9 + 9;
   MMB_REQUIRE(n_slots == expect, "mmb_fused_uni_train_backward: %d slots given, the architecture has %d", n_slots,
               expect);
   BwdArgs A{packed_bwd, reinterpret_cast<const BDesc*>(desc_bwd), num_blocks, 0, use_skip, B, N, maskf,
@@ -473,7 +470,7 @@ extern "C" int mmb_fused_epic_train_backward(int variant, int B, int N, const fl
   MMB_REQUIRE(packed_bwd && desc_bwd && maskf && counts && slots, "mmb_fused_epic_train_backward: NULL argument");
   MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_epic_train_backward: unknown variant %d", variant);
   MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_fused_epic_train_backward: dropout p=%f outside [0,1)", drop_p);
-  const int per_layer = use_skip ? 10 : 9;
+  const int per_layer = 9;
   const int expect = 4 + 8 + (1 + nb_fused_exec * per_layer) + 2 * (1 + nb_branch * per_layer + 9) + 1;
   MMB_REQUIRE(n_slots == expect, "mmb_fused_epic_train_backward: %d slots given, the architecture has %d", n_slots,
               expect);

@@ -86,12 +86,14 @@ def _encoder(pl, enc, tseg, x_local, x_global, out, out_slot=True):
         p, off = pl.next_offset()
         g2 = pl.linear(ly.fc_glob2, 1, [(gh, SEG_ROW)], res1=x_global, post="lrelu", res2=skip_g, y1=g_new, y2=g_out,
                        p=p, off=off)
+        sgn_lh = pl.jets(512)                    # 256 x 64-bit words per jet: sign bits for the reverse kernel
         lh = pl.rows(ly.fc_loc1.dim_out)
         l1 = pl.linear(ly.fc_loc1, N, [tseg, (x_local, SEG_ROW), (g_new, SEG_JET)], act="lrelu", y1=lh)
+        sgn_y1 = pl.jets(512)
         l_out = pl.rows(H)
         p, off = pl.next_offset()
         l2 = pl.linear(ly.fc_loc2, N, [(lh, SEG_ROW)], res1=x_local, post="lrelu", res2=skip_l, y2=l_out, p=p, off=off)
-        rec["layers"].append({"g1": g1, "g2": g2, "l1": l1, "l2": l2})
+        rec["layers"].append({"g1": g1, "g2": g2, "l1": l1, "l2": l2, "sgn_lh": sgn_lh, "sgn_y1": sgn_y1})
         x_local, x_global = l_out, g_out
     if out_slot:
         pl.slot(out)
@@ -172,14 +174,11 @@ class _Grads:
 def _layers_bwd(rec, use, rows, jets, jobs):
     """slots + jobs of the executed EPiC layers of one encoder, last layer first (the kernel's order)"""
     for lr in reversed(rec["layers"]):
-        l_out = lr["l2"]["y2"]
-        H = l_out.shape[1]
+        H = lr["l2"]["y2"].shape[1]
         G = lr["g2"]["y1"].shape[1]
-        use(l_out)
-        if rec["skip"] is not None:
-            use(rec["skip"])
+        use(lr["sgn_y1"])
         dz_l2 = rows(H)
-        use(lr["l1"]["y1"])
+        use(lr["sgn_lh"])
         dz_l1, S_l1 = rows(H), jets(H)
         use(lr["g2"]["y1"])
         dz_g2 = jets(G)

@@ -327,15 +327,19 @@ grad_weight_rows_body(int M, const float* __restrict__ X, int64_t x_ld, int K, c
   __syncthreads();
   if (wave == 2) each([](float* slot, float v) { *slot += v; return v; });
   __syncthreads();
-  if (wave == 3) each([](float* slot, float v) { return v + *slot; });
-  if (wave == 3) {
-    sfor<OT>([&](auto oc) { sfor<KT>([&](auto kc) {
-      constexpr int ot = decltype(oc)::v, kt = decltype(kc)::v;
+  if (wave == 3) each([](float* slot, float v) { *slot += v; return v; });
+  __syncthreads();
+  // flush: the OT*KT summed tiles are shared out over the four waves (one wave alone issued 16*OT*KT
+  // atomics per lane back to back: a third of the kernel's time at 512 rows per block)
+  sfor<OT>([&](auto oc) { sfor<KT>([&](auto kc) {
+    constexpr int ot = decltype(oc)::v, kt = decltype(kc)::v;
+    if (((ot * KT + kt) & 3) == wave) {
       const int col = k0 + 32 * kt + i32;
       sfor<16>([&](auto ec) { constexpr int e = decltype(ec)::v;
         const int o = o0 + 32 * ot + (e & 3) + 8 * (e >> 2) + 4 * half;
-        if (o < Nout && col < K) atomicAdd(&dW[(int64_t)o * dw_ld + col], acc[ot][kt][e]); }); }); });
-  }
+        if (o < Nout && col < K) atomicAdd(&dW[(int64_t)o * dw_ld + col], lds[((ot * KT + kt) * 16 + e) * 64 + lane]); });
+    } }); });
+  __syncthreads();                                       // (db below reuses lds)
   // db: one atomic per column and BLOCK (same-address atomics serialise at the memory side: ~60 ns each)
   if (db != nullptr && by == 0) {
     sfor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;

@@ -317,7 +317,9 @@ class Workspace:
         self.temb = torch.empty(B, e.dim_emb_time, dtype=torch.float32, device=dev)
         self.cont = None if self.uni else torch.empty(M, e.dim_emb_continuous, dtype=torch.float32, device=dev)
         self.disc = torch.empty(M, e.dim_emb_discrete, dtype=torch.float32, device=dev)
-        self.d_hc = None if self.uni else torch.empty(M, 3, dtype=torch.float32, device=dev)
+        # (B*N, 4) with a zero 4th column: 16-byte rows put the continuous head's weight gradient on the row-streaming
+        # kernel (a 12-byte pitch falls back to the generic one)
+        self.d_hc = None if self.uni else torch.zeros(M, 4, dtype=torch.float32, device=dev)
         self.d_hd = torch.empty(M, 8, dtype=torch.float32, device=dev)
         pl = _Plan(B, N, dev, [], 0.0, 0)
         _plan_forward(model, pl, self.temb, self.cont, self.disc, None, self.d_hd if self.uni else None)
@@ -354,17 +356,21 @@ class Workspace:
                 if row_seg:
                     first = False
                 if ops.gw_fast(t, Z):
-                    cls = ops.gw_class(Ks, Nout)
-                    lst = probs.setdefault(cls, [[], 0])
-                    rec, n = ops.gw_record(t, Z, dWs, db, reps, dWr.stride(0), dbr.stride(0), lst[1])
-                    lst[0].append(rec)
-                    lst[1] += n
+                    probs.setdefault(ops.gw_class(Ks, Nout), []).append((t, Z, dWs, db, reps, dWr.stride(0),
+                                                                         dbr.stride(0)))
                 else:
                     self.generic.append((t, Z, dWs, db, reps, dWr.stride(0), dbr.stride(0)))
                 koff += Ks
             self.layers.append((r["layer"], dWr, dbr, R))
-        self.gw = [(cls, torch.tensor(recs, dtype=torch.int64).to(dev), len(recs), nblk)
-                   for cls, (recs, nblk) in sorted(probs.items())]
+        self.gw = []
+        for cls, plist in sorted(probs.items()):
+            rpb = ops.gw_rows_per_block([(q[0].shape[0], q[0].shape[1], q[1].shape[1]) for q in plist])
+            recs, nblk = [], 0
+            for q in plist:
+                rec, n = ops.gw_record(*q, nblk, rpb_big=rpb)
+                recs.append(rec)
+                nblk += n
+            self.gw.append((cls, torch.tensor(recs, dtype=torch.int64).to(dev), len(recs), nblk))
         self.pack = pack
         self.grad_ptrs = None
         self.own_grads = None
@@ -437,7 +443,7 @@ class Workspace:
         from mmb_hip import ops
         M = self.pl.M
         if not self.uni:
-            self.d_hc.copy_(d_hc.reshape(M, -1))
+            self.d_hc[:, :3].copy_(d_hc.reshape(M, -1))
         self.d_hd.copy_(d_hd.reshape(M, -1))
         pack = self.pack
         pbwd = fused_epic.packed_bwd(pack, fused_epic.params_version(model))

@@ -1,6 +1,7 @@
 """Tensor-level wrappers over the C ABI: validate device/dtype/contiguity, allocate outputs
 with torch (plumbing only), enqueue on torch's current HIP stream.  No host syncs."""
 import ctypes as C
+import os
 
 import torch
 
@@ -435,12 +436,30 @@ def gw_fast(X, dZ):
             and X.data_ptr() % 16 == 0 and dZ.data_ptr() % 16 == 0 and X.stride(1) == 1 and dZ.stride(1) == 1)
 
 
-def gw_record(X, dZ, dW, db, replicas, rep_stride, db_stride, block_begin):
+def gw_rows_per_block(problems):
+    """Rows per block for the big (M > 16384) problems of ONE multi launch: every block ends with an LDS reduction and
+    16*OT*KT atomics per lane, so blocks should be as long as the launch can afford while still filling the chip
+    (>= 2 x 256 CUs x 3 resident blocks).  problems: iterable of (M, K, Nout)."""
+    env = os.environ.get("MMB_GW_RPB")
+    if env:
+        return int(env)
+    for rpb in (2048, 1024):
+        blocks = 0
+        for M, K, Nout in problems:
+            OTb, KTb = gw_class(K, Nout)
+            r = 64 if M <= 16384 else rpb
+            blocks += ((M + r - 1) // r) * (((K + 31) // 32 + KTb - 1) // KTb) * (((Nout + 31) // 32 + OTb - 1) // OTb)
+        if blocks >= 1536:
+            return rpb
+    return 512
+
+
+def gw_record(X, dZ, dW, db, replicas, rep_stride, db_stride, block_begin, rpb_big=512):
     """One GwProb record (list of 18 ints) + the number of blocks it takes."""
     M, K = X.shape
     Nout = dZ.shape[1]
     OTb, KTb = gw_class(K, Nout)
-    rpb = 64 if M <= 16384 else 512
+    rpb = 64 if M <= 16384 else rpb_big
     nbx = (M + rpb - 1) // rpb
     nby = ((K + 31) // 32 + KTb - 1) // KTb
     nbz = ((Nout + 31) // 32 + OTb - 1) // OTb

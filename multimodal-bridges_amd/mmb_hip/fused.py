@@ -447,6 +447,8 @@ def refresh_flat(pack, version):
 def repack(pack, version):
     """Refresh the packed parameter buffer after an optimizer step (same architecture, new values)."""
     flat = refresh_flat(pack, version)
+    pack.pop("grid_key", None)                               # cached time-grid tables were built from the old weights
+    pack.pop("grid", None)
     torch.index_select(flat, 0, pack["gather"], out=pack["packed"])
     if pack["gather2"] is not None:
         pack["packed"].add_(flat.index_select(0, pack["gather2"]))

@@ -428,3 +428,34 @@ def test_fused_training_other_depths(golden, name, blocks, skip):
             close(gf[n], gl[n], rtol=2e-3, atol=2e-4 * scale + 1e-7)
         except AssertionError as e:
             raise AssertionError(f"gradient of {n}: {e}") from None
+
+
+@pytest.mark.parametrize("name", ["mm_mid", "uni_mid"])
+def test_generation_after_parameter_update(golden, name):
+    """The packed buffers are refreshed IN PLACE after an optimizer step; everything cached beside them (the per-grid
+    time-embedding / time-vector tables of the generation loop) must be rebuilt too: generating, updating the
+    parameters and generating again must equal a freshly built model with the updated parameters."""
+    from tensorclass import TensorMultiModal
+    from datamodules.datasets import DataCoupling
+    g = golden(name)
+    model = build(g, num_timesteps=6)
+    multi = name.startswith("mm")
+    B, N = 32, 16
+    mask = torch.ones(B, N, 1, dtype=torch.int64, device="cuda")
+    tgt = TensorMultiModal(None, torch.zeros(B, N, 3, device="cuda") if multi else None,
+                           torch.zeros(B, N, 1, dtype=torch.int64, device="cuda"), mask)
+    model.manual_seed(5)
+    model.predict_step(DataCoupling(TensorMultiModal(), tgt, None), 0)            # fills the caches
+    gen = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=gen).cuda())
+    model.manual_seed(5)
+    got, _ = model.predict_step(DataCoupling(TensorMultiModal(), tgt, None), 0)
+    fresh = build(g, num_timesteps=6)
+    fresh.load_state_dict(model.state_dict())
+    fresh.manual_seed(5)
+    want, _ = fresh.predict_step(DataCoupling(TensorMultiModal(), tgt, None), 0)
+    assert torch.equal(got.discrete, want.discrete)
+    if multi:
+        assert torch.equal(got.continuous, want.continuous)

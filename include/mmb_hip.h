@@ -288,6 +288,11 @@ int mmb_grad_weight_rows(int M, const float* X, int64_t x_ld, int K, const float
                          int Nout, float* dW, int64_t dw_ld, float* db,
                          int replicas, int64_t rep_stride, int64_t db_stride, void* stream);
 
+/* The same for a very narrow input (K <= 4, Nout <= 32): the continuous embedding nn.Linear(dim_continuous, Ec) of
+ * embedder.py:57 -- a streaming reduction instead of an MFMA tile that would be 29/32 padding.  Accumulates. */
+int mmb_grad_weight_smallk(int M, const float* X, int64_t x_ld, int K, const float* dZ, int64_t dz_ld, int Nout,
+                           float* dW, int64_t dw_ld, float* db, void* stream);
+
 /* ---- one launch for all layers of a model (a training step re-normalises ~60 small matrices and has ~100
  * weight-gradient problems: launch-bound otherwise).  The tables live in device memory and hold 8-byte fields only
  * (built on the host as int64 tensors).

@@ -407,9 +407,58 @@ grad_weight_rows_multi_kernel(const GwProb* __restrict__ probs, int n_probs) {
                                 (int)q.rpb, (int)q.replicas, q.rep_stride, q.db_stride, bx, by, bz);
 }
 
+// dW[o][k] += sum_rows dZ[row][o] X[row][k], db[o] += sum_rows dZ[row][o] for a VERY narrow input (K <= 4: the
+// continuous embedding, Linear(3 -> Ec), embedder.py:57): an MFMA tile would be 29/32 padding, so this is a plain
+// streaming reduction -- one (o, row-slice) per lane, K+1 accumulators, one atomic per lane group at the end.
+__global__ void __launch_bounds__(256)
+grad_weight_smallk_kernel(int M, const float* __restrict__ X, int64_t x_ld, int K, const float* __restrict__ dZ,
+                          int64_t dz_ld, int Nout, float* __restrict__ dW, int64_t dw_ld, float* __restrict__ db) {
+  // thread = (row lane r of 256/NP, output o): NP = Nout rounded up to a power of two <= 32
+  int NP = 1;
+  while (NP < Nout) NP <<= 1;
+  const int o = threadIdx.x % NP, r = threadIdx.x / NP, RL = 256 / NP;
+  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (o < Nout)
+    for (int64_t row = (int64_t)blockIdx.x * RL + r; row < M; row += (int64_t)gridDim.x * RL) {
+      const float z = dZ[row * dz_ld + o];
+      acc[4] += z;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < K) acc[k] += z * X[row * x_ld + k];
+    }
+  __shared__ float red[5][256];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  if (r == 0 && o < Nout) {
+    float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < RL; ++j)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) s[k] += red[k][j * NP + o];
+    for (int k = 0; k < K; ++k) atomicAdd(&dW[(int64_t)o * dw_ld + k], s[k]);
+    if (db != nullptr) atomicAdd(&db[o], s[4]);
+  }
+}
+
 }  // namespace mmb
 
 using namespace mmb;
+
+extern "C" int mmb_grad_weight_smallk(int M, const float* X, int64_t x_ld, int K, const float* dZ, int64_t dz_ld,
+                                      int Nout, float* dW, int64_t dw_ld, float* db, void* stream) {
+  MMB_REQUIRE(M > 0 && K >= 1 && K <= 4 && Nout >= 1 && Nout <= 32, "mmb_grad_weight_smallk: needs K <= 4, Nout <= 32 (K=%d Nout=%d)", K, Nout);
+  MMB_REQUIRE(X && dZ && dW && x_ld >= K && dz_ld >= Nout && dw_ld >= K, "mmb_grad_weight_smallk: bad argument");
+  int NP = 1;
+  while (NP < Nout) NP <<= 1;
+  const int rows_per_pass = 256 / NP;                       // rows a block covers per loop iteration
+  // every block ends with one atomic per (o, k) on the SAME few addresses (they serialise at the memory side,
+  // ~60 ns each), so few, long blocks: ~32 iterations per thread, at most 256 blocks
+  int grid = (M + rows_per_pass * 32 - 1) / (rows_per_pass * 32);
+  if (grid > 256) grid = 256;
+  hipLaunchKernelGGL(grad_weight_smallk_kernel, dim3(grid), dim3(256), 0, as_stream(stream), M, X, x_ld, K, dZ, dz_ld,
+                     Nout, dW, dw_ld, db);
+  return check_launch("mmb_grad_weight_smallk");
+}
 
 // probs: device table of n_probs GwProb records of tile class (OTb, KTb) (see mmb_hip.ops.gw_class), ranges of
 // linear block ids ascending and contiguous from 0 to total_blocks.

@@ -226,7 +226,11 @@ def _embed_bwd(e, store, mi):
         d_pre = g_c * mi_.maskf.reshape(-1, 1)
         dW = torch.zeros_like(ce.weight)
         db = torch.zeros_like(ce.bias)
-        ops.grad_weight([(x.reshape(-1, x.shape[-1]), SEG_ROW)], mi_.N, None, d_pre, dW, db)
+        xr = x.reshape(-1, x.shape[-1])
+        if xr.shape[1] <= 4 and d_pre.shape[1] <= 32:
+            ops.grad_weight_smallk(xr, d_pre, dW, db)
+        else:
+            ops.grad_weight([(xr, SEG_ROW)], mi_.N, None, d_pre, dW, db)
         _acc_param(ce.weight, dW)
         _acc_param(ce.bias, db)
 

@@ -64,6 +64,8 @@ SIGNATURES = {
                                      C.c_int, C.c_float, C.c_uint64, C.c_uint64, c_f32p, c_f32p, c_stream],
     "mmb_fused_epic_train_backward": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, c_f32p,
                                       c_i32p, C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint64, c_stream],
+    "mmb_grad_weight_smallk": [C.c_int, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p,
+                               c_stream],
     "mmb_weight_norm_multi": [C.c_int, C.c_void_p, c_stream],
     "mmb_weight_norm_bwd_multi": [C.c_int, C.c_void_p, c_stream],
     "mmb_grad_weight_rows_multi": [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, c_stream],

@@ -506,3 +506,14 @@ def wasserstein_1d(a, b):
     ca = torch.searchsorted(a, allv[:-1], right=True).double() / a.numel()
     cb = torch.searchsorted(b, allv[:-1], right=True).double() / b.numel()
     return ((ca - cb).abs() * deltas).sum()
+
+
+def grad_weight_smallk(X, dZ, dW, db=None):
+    """dW (Nout,K) += dZ^T @ X, db += colsum(dZ) for K <= 4, Nout <= 32 (rows may be strided)."""
+    for t, name in ((X, "X"), (dZ, "dZ"), (dW, "dW")):
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+            raise MMBError(f"grad_weight_smallk: {name} must be a 2-D float32 HIP tensor with unit inner stride")
+    if X.shape[0] != dZ.shape[0] or dW.shape != (dZ.shape[1], X.shape[1]):
+        raise MMBError("grad_weight_smallk: shape mismatch")
+    call("mmb_grad_weight_smallk", X.shape[0], X.data_ptr(), X.stride(0), X.shape[1], dZ.data_ptr(), dZ.stride(0),
+         dZ.shape[1], dW.data_ptr(), dW.stride(0), db.data_ptr() if db is not None else None, stream())

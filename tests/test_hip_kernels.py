@@ -477,3 +477,16 @@ def test_jet_observables_and_w1(ops):
     a, b = torch.randn(1000, generator=g), torch.randn(777, generator=g) * 1.3 + 0.2
     w = float(ops.wasserstein_1d(dev(a), dev(b)))
     assert abs(w - scipy.stats.wasserstein_distance(a.numpy(), b.numpy())) < 1e-6
+
+
+@pytest.mark.parametrize("M,K,Nout", [(131072, 3, 16), (1000, 3, 8), (77, 4, 32), (5000, 1, 5)])
+def test_grad_weight_smallk(ops, M, K, Nout):
+    g = torch.Generator().manual_seed(M + K)
+    X = torch.randn(M, K, generator=g).cuda()
+    dZ = torch.randn(M, Nout + 2, generator=g).cuda()[:, 1:1 + Nout]
+    dW = torch.full((Nout, K), 0.5, device="cuda")
+    db = torch.full((Nout,), -2.0, device="cuda")
+    ops.grad_weight_smallk(X, dZ, dW, db)
+    want = dZ.double().t() @ X.double()
+    close(dW.double() - 0.5, want, rtol=1e-4, atol=2e-5 * float(want.abs().max()))
+    close(db.double() + 2.0, dZ.double().sum(0), rtol=1e-4, atol=2e-5 * float(dZ.abs().sum(0).max()))

@@ -336,51 +336,86 @@ __device__ __forceinline__ float4 wload(WRsrc R, int woff, int f4, int lane16) {
 // First A-operand group (k-steps 0..3 of every output tile) of a packed weight matrix, fetched
 // ahead of the GEMM that uses it -- while the previous GEMM or the per-jet chain runs -- so that no
 // GEMM starts with an exposed L2 round trip.
+// ---- fp32 GEMMs on the bf16 matrix cores.  gfx950 has no reduced-precision f32 MFMA mode and its f32 MFMA runs at
+// 1/16 of the bf16 rate, so every f32 operand is split into three bf16 planes (hi + mid + lo = the whole 24-bit
+// significand; each residual is exact in f32) and the product is the six partial products of weight >= 2^-16:
+// Wl xh + Wm xm + Wh xl + Wm xh + Wh xm + Wh xh (each bf16 x bf16 product is exact in f32, accumulation in f32, smallest
+// terms first).  The three dropped products are below 2^-24 of the result: the sum is an fp32 GEMM to within the
+// rounding of its accumulation order.  v_mfma_f32_32x32x16_bf16 retires 16 k-values in 32 cycles against 8 x 64
+// cycles of v_mfma_f32_32x32x2_f32: the six of them cost 192 cycles instead of 512.  Registers 8jj..8jj+7 of an input tile are one B operand (k-slot (half, j) =
+// feature 16 jj + 8 (j >> 2) + 4 half + (j & 3)); the weights are pre-split and packed to match:
+// [KT][2][OT][3 planes][64 lanes][8 bf16].
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+struct Frag16 {
+  float4 p[3];
+};
 template <int OT>
 struct AFrag {
-  float4 a[OT];
+  static constexpr int N = OT == 1 ? 2 : 3;
+  Frag16 a[N];
 };
 template <int OT>
 __device__ __forceinline__ void mma_prefetch(AFrag<OT>& f, WRsrc R, int woff, int lane) {
-  ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; f.a[ot] = wload(R, woff, ot * 64, lane * 16); });
+  ffor<AFrag<OT>::N>([&](auto gc) { constexpr int g = decltype(gc)::v;
+    ffor<3>([&](auto pc) { constexpr int pl = decltype(pc)::v; f.a[g].p[pl] = wload(R, woff, (g * 3 + pl) * 64, lane * 16); }); });
 }
-
-// acc[ot] += W_x (tile rows ot) * X^T, X^T tiles delivered by `tile(IF<ft>)` (a reference to
-// registers, or a value fetched from LDS).  A-operand groups (4 k-steps x OT tiles, one dwordx4 per
-// lane and tile) run D groups ahead of the MFMAs through a ring of D+1 register buffers; D is
-// chosen so that the look-ahead is ~1000 MFMA cycles whatever OT is.
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+  const bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+// 8 floats -> three bf16x8 planes
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+  uint32_t ph[4], pm[4], pq[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = v[2 * j], b = v[2 * j + 1];
+    ph[j] = pk_bf16(a, b);
+    const float ra = a - __builtin_bit_cast(float, ph[j] << 16), rb = b - __builtin_bit_cast(float, ph[j] & 0xFFFF0000u);
+    pm[j] = pk_bf16(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, pm[j] << 16), sb = rb - __builtin_bit_cast(float, pm[j] & 0xFFFF0000u);
+    pq[j] = pk_bf16(sa, sb);
+  }
+  typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+  const u32x4v H = {ph[0], ph[1], ph[2], ph[3]}, M = {pm[0], pm[1], pm[2], pm[3]}, L = {pq[0], pq[1], pq[2], pq[3]};
+  h = __builtin_bit_cast(bf16x8, H);
+  m = __builtin_bit_cast(bf16x8, M);
+  l = __builtin_bit_cast(bf16x8, L);
+}
 template <int KT, int OT, typename TileFn>
 __device__ __forceinline__ void mma_x(f32x16 (&acc)[OT], TileFn&& tile, WRsrc R, int woff, int lane,
                                       const AFrag<OT>& pre) {
-  constexpr int NG = KT * 4;
-  constexpr int D0 = OT >= 4 ? 1 : (OT == 2 ? 2 : 4);
-  constexpr int D = D0 < NG - 1 ? D0 : (NG - 1 > 0 ? NG - 1 : 1);
+  constexpr int NG = KT * 2 * OT;
+  constexpr int D = AFrag<OT>::N;
+  static_assert(NG >= D, "prefetch deeper than the GEMM");
   const int lane16 = lane * 16;
-  float4 ring[D + 1][OT];
-  ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; ring[0][ot] = pre.a[ot]; });
-  ffor<D - 1>([&](auto dc) {
-    constexpr int g = 1 + decltype(dc)::v;
-    if constexpr (g < NG)
-      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v; ring[g][ot] = wload(R, woff, (g * OT + ot) * 64, lane16); });
-  });
+  Frag16 ring[D + 1];
+  ffor<D>([&](auto gc) { constexpr int g = decltype(gc)::v; ring[g] = pre.a[g]; });
   ffor<KT>([&](auto fc) {
     constexpr int ft = decltype(fc)::v;
     decltype(auto) xt = tile(IF<ft>{});
-    ffor<4>([&](auto qc) {
-      constexpr int q = decltype(qc)::v;          // group = (ft, q): four k-steps r = 4q..4q+3
-      constexpr int g = ft * 4 + q;
-      constexpr int cur = g % (D + 1);
-      if constexpr (g + D < NG)
-        ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-          ring[(g + D) % (D + 1)][ot] = wload(R, woff, ((g + D) * OT + ot) * 64, lane16); });
-      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[cur][ot].x, xt[4 * q + 0], acc[ot], 0, 0, 0); });
-      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[cur][ot].y, xt[4 * q + 1], acc[ot], 0, 0, 0); });
-      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[cur][ot].z, xt[4 * q + 2], acc[ot], 0, 0, 0); });
-      ffor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[cur][ot].w, xt[4 * q + 3], acc[ot], 0, 0, 0); });
+    ffor<2>([&](auto jc) {
+      constexpr int jj = decltype(jc)::v;
+      const float v[8] = {xt[8 * jj + 0], xt[8 * jj + 1], xt[8 * jj + 2], xt[8 * jj + 3],
+                          xt[8 * jj + 4], xt[8 * jj + 5], xt[8 * jj + 6], xt[8 * jj + 7]};
+      bf16x8 bh, bm, bl;
+      split8(v, bh, bm, bl);
+      ffor<OT>([&](auto oc) {
+        constexpr int ot = decltype(oc)::v;
+        constexpr int g = (ft * 2 + jj) * OT + ot;
+        constexpr int cur = g % (D + 1);
+        if constexpr (g + D < NG)
+          ffor<3>([&](auto pc) { constexpr int pl = decltype(pc)::v;
+            ring[(g + D) % (D + 1)].p[pl] = wload(R, woff, ((g + D) * 3 + pl) * 64, lane16); });
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, ring[cur].p[0]), am = __builtin_bit_cast(bf16x8, ring[cur].p[1]),
+                     al = __builtin_bit_cast(bf16x8, ring[cur].p[2]);
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[ot], 0, 0, 0);
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[ot], 0, 0, 0);
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[ot], 0, 0, 0);
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[ot], 0, 0, 0);
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[ot], 0, 0, 0);
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[ot], 0, 0, 0);
+      });
     });
   });
 }

@@ -11,6 +11,7 @@ kernel):
 Every chunk starts on a 16-byte boundary.  The layer order is the order the kernel walks.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -126,6 +127,7 @@ class _Packer:
         self.time_lins = []
         self.second = []              # index mode: (offset, indices) of blocks that are ADDED on top (time_twice)
         self.mfma_flops = []          # 2*K_pad*O_pad of every per-particle layer (what the MFMAs execute)
+        self.xchunks, self.nfrag = [], 0   # MFMA operands: fragments of 64 lanes x 8 values, split into bf16 planes last
 
     def add(self, t):
         t = t.contiguous().reshape(-1).float()
@@ -139,13 +141,33 @@ class _Packer:
 
     @staticmethod
     def pack_x(W):
-        """(O,Kx) -> MFMA fragment order, zero padded to multiples of 32."""
+        """(O,Kx) -> (fragments, 512) in MFMA operand order, zero padded to multiples of 32: fragment (ft, jj, ot)
+        holds, for lane (hk, i) and slot j = (qq, e), W[32 ot + i][32 ft + 16 jj + 8 qq + 4 hk + e] -- the A operand of
+        one v_mfma_f32_32x32x16_bf16 whose B operand is registers 8jj..8jj+7 of input tile ft (fused_common.h)."""
         O, K = W.shape
         OT, KT = (O + 31) // 32, (K + 31) // 32
         Wp = torch.zeros(OT * 32, KT * 32, device=W.device)
         Wp[:O, :K] = W
-        v = Wp.view(OT, 32, KT, 4, 2, 4)                 # (ot, i, ft, q, hk, e)
-        return v.permute(2, 3, 0, 4, 1, 5).contiguous()  # (ft, q, ot, hk, i, e)
+        v = Wp.view(OT, 32, KT, 2, 2, 2, 4)              # (ot, i, ft, jj, qq, hk, e)
+        return v.permute(2, 3, 0, 5, 1, 4, 6).reshape(KT * 2 * OT, 512)
+
+    def add_x(self, W):
+        """-> marker resolved by finish(): float offset of this matrix's first fragment in the packed buffer"""
+        u = self.pack_x(W)
+        start = self.nfrag
+        self.xchunks.append(u)
+        self.nfrag += u.shape[0]
+        self.mfma_flops.append(2 * u.numel())
+        return ("x", start)
+
+    def finish(self):
+        """-> (main floats, (F,512) MFMA operand values, int32 descriptors with the fragment markers resolved)"""
+        main = torch.cat(self.chunks)
+        xs = torch.cat(self.xchunks)
+        n_main = main.numel()
+        assert n_main % 4 == 0
+        rows = [[n_main + v[1] * FRAG_FLOATS if isinstance(v, tuple) else v for v in row] for row in self.desc]
+        return main, xs, torch.tensor(rows, dtype=torch.int32, device=self.device).reshape(-1)
 
     def bias(self, b):
         O = b.numel()
@@ -170,9 +192,7 @@ class _Packer:
         if n_t:
             self.time_parts.append(Wt)
             self.time_lins.append((lin, n_t, time_twice))
-        packed_x = self.pack_x(W[:, n_t:n_t + n_x])
-        self.mfma_flops.append(2 * packed_x.numel())
-        wx = self.add(packed_x)
+        wx = self.add_x(W[:, n_t:n_t + n_x])
         wg = self.add(W[:, n_t + n_x:].t()) if n_g else -1
         self.desc.append([wx, wt, wg, self.bias(lin.bias.detach())])
 
@@ -201,7 +221,7 @@ class _Packer:
             else:
                 Wt = Wt + W[:, n_t:2 * n_t]
             W = W[:, n_t:]
-        a = self.add(self.pack_x(W[:, n_t:n_t + n_x].t()))
+        a = self.add_x(W[:, n_t:n_t + n_x].t())
         if time_twice and isinstance(lin, _IdxLin):
             self.second[-1] = (self.n, self.second[-1][1])
         b = self.add(rows(Wt)) if n_t else -1
@@ -236,9 +256,8 @@ def _pack_uni(model, variant, src):
         pk.particle_layer(L(ly.fc_loc2), 0, H, 0)
     pk.particle_layer(L(enc.output_layer), Et, H, G)
     off_table = pk.add(src.tensor(emb.discrete_embedding.table, emb.discrete_embedding))
-    packed = torch.cat(pk.chunks)
-    desc = torch.tensor(pk.desc, dtype=torch.int32, device=dev).reshape(-1)
-    return {"kind": "uni", "packed": packed, "desc": desc, "variant": variant, "num_blocks": enc.num_blocks,
+    main, xs, desc = pk.finish()
+    return {"kind": "uni", "main": main, "xs": xs, "desc": desc, "variant": variant, "num_blocks": enc.num_blocks,
             "nb_branch": enc.num_blocks, "nb_fused_exec": 0,
             "use_skip": int(bool(cfg.encoder.skip_connection)), "off_table": off_table, "time_parts": pk.time_parts,
             "time_lins": pk.time_lins, "second": pk.second, "mfma_flops_per_forward": sum(pk.mfma_flops)}
@@ -264,8 +283,7 @@ def _pack_uni_bwd(model, src):
         pk.particle_layer_bwd(L(ly.fc_loc1), Et, H, G)
         pk.particle_layer_bwd(L(ly.fc_loc2), 0, H, 0)
     pk.particle_layer_bwd(L(enc.output_layer), Et, H, G)
-    desc = torch.tensor(pk.desc, dtype=torch.int32, device=dev).reshape(-1)
-    return torch.cat(pk.chunks), desc, pk.second
+    return pk.finish() + (pk.second,)
 
 
 def _gather_maps(imap, second, n_flat):
@@ -294,23 +312,48 @@ def pack_model(model):
         fwd = _pack_multi
         bwd = lambda m, sb: _pack_multi_bwd(m, sb) + ([],)
     pack = fwd(model, variant, _RealSource())
-    src = _IndexSource(pack["packed"].device)
+    dev = pack["main"].device
+    pack["n_main"] = pack["main"].numel()
+    pack["packed"] = torch.cat([pack.pop("main"), split_planes(pack.pop("xs"))])
+    src = _IndexSource(dev)
     im = fwd(model, variant, src)
-    imap = im["packed"]
-    assert imap.numel() == pack["packed"].numel()
-    pack["gather"], pack["gather2"] = _gather_maps(imap, im.get("second"), src.n)
+    assert im["main"].numel() == pack["n_main"]
+    pack["gather"], pack["gather2"] = _gather_maps(im["main"], im.get("second"), src.n)
+    pack["gather_x"] = _gather_maps(im["xs"].reshape(-1), None, src.n)[0]
     pack["getters"] = src.getters
     pack["items"], pack["n_flat"] = src.items, src.n
     pack["flat"] = None                                    # persistent [all sources | 0], see refresh_flat
-    pack["zero"] = torch.zeros(1, dtype=torch.float32, device=imap.device)
-    # backward weights (training): same sources, so the same flat buffer feeds a second gather
-    srcb = _IndexSource(imap.device)
-    bmap, pack["desc_bwd"], second_b = bwd(model, srcb)
+    pack["zero"] = torch.zeros(1, dtype=torch.float32, device=dev)
+    # backward weights (training): same sources, so the same flat buffer feeds a second set of gathers
+    srcb = _IndexSource(dev)
+    bmain, bxs, pack["desc_bwd"], second_b = bwd(model, srcb)
     assert srcb.n == src.n - _tail_sources(model)
-    pack["gather_bwd"], pack["gather2_bwd"] = _gather_maps(bmap, second_b, src.n)
+    pack["n_main_bwd"] = bmain.numel()
+    pack["gather_bwd"], pack["gather2_bwd"] = _gather_maps(bmain, second_b, src.n)
+    pack["gather_x_bwd"] = _gather_maps(bxs.reshape(-1), None, src.n)[0]
     pack["packed_bwd"] = None                              # built on first training use
     pack["bwd_version"] = None
     return pack
+
+
+FRAG_FLOATS = 768      # one MFMA operand fragment in the packed buffer: 3 bf16 planes x 64 lanes x 8 values = 3072 B
+
+
+def split_planes(xs):
+    """(F, 512) f32 operand values -> flat f32 view of (F, 3, 64 lanes, 8) bf16: hi + mid + lo = the value's 24-bit
+    significand (round-to-nearest splits; every residual is exact in f32)."""
+    hi = xs.bfloat16()
+    r = xs - hi.float()
+    mid = r.bfloat16()
+    lo = (r - mid.float()).bfloat16()
+    return torch.stack([hi, mid, lo], dim=1).contiguous().view(torch.float32).reshape(-1)
+
+
+def _fill_packed(dst, n_main, flat, gather, gather2, gather_x):
+    torch.index_select(flat, 0, gather, out=dst[:n_main])
+    if gather2 is not None:
+        dst[:n_main].add_(flat.index_select(0, gather2))
+    dst[n_main:] = split_planes(flat.index_select(0, gather_x).view(-1, 512))
 
 
 def _tail_sources(model):
@@ -327,11 +370,10 @@ def packed_bwd(pack, version):
     if pack["bwd_version"] != version:
         flat = refresh_flat(pack, version)
         if pack["packed_bwd"] is None:
-            pack["packed_bwd"] = flat.index_select(0, pack["gather_bwd"])
-        else:
-            torch.index_select(flat, 0, pack["gather_bwd"], out=pack["packed_bwd"])
-        if pack["gather2_bwd"] is not None:
-            pack["packed_bwd"].add_(flat.index_select(0, pack["gather2_bwd"]))
+            n = pack["n_main_bwd"] + pack["gather_x_bwd"].numel() * 3 // 2
+            pack["packed_bwd"] = torch.empty(n, dtype=torch.float32, device=flat.device)
+        _fill_packed(pack["packed_bwd"], pack["n_main_bwd"], flat, pack["gather_bwd"], pack["gather2_bwd"],
+                     pack["gather_x_bwd"])
         pack["bwd_version"] = version
     return pack["packed_bwd"]
 
@@ -371,8 +413,7 @@ def _pack_multi_bwd(model, src):
     for head in (enc.continuous_head, enc.discrete_head):
         pk.particle_layer_bwd(L(head["0"]), Et, half + H0, 0)
         pk.particle_layer_bwd(L(head["2"]), 0, H0, 0)
-    desc = torch.tensor(pk.desc, dtype=torch.int32, device=dev).reshape(-1)
-    return torch.cat(pk.chunks), desc
+    return pk.finish()
 
 
 def _flat_rows(pack):
@@ -449,9 +490,7 @@ def repack(pack, version):
     flat = refresh_flat(pack, version)
     pack.pop("grid_key", None)                               # cached time-grid tables were built from the old weights
     pack.pop("grid", None)
-    torch.index_select(flat, 0, pack["gather"], out=pack["packed"])
-    if pack["gather2"] is not None:
-        pack["packed"].add_(flat.index_select(0, pack["gather2"]))
+    _fill_packed(pack["packed"], pack["n_main"], flat, pack["gather"], pack["gather2"], pack["gather_x"])
     pack["time_parts"] = [(l.weight()[:, :n_t] + l.weight()[:, n_t:2 * n_t]) if twice else l.weight()[:, :n_t]
                           for l, n_t, twice in pack["time_lins"]]
     return pack
@@ -497,9 +536,8 @@ def _pack_multi(model, variant, src):
     off_cw = pk.add(src.tensor(emb.continuous_embedding.weight.detach, emb.continuous_embedding.weight))
     off_cb = pk.add(src.tensor(emb.continuous_embedding.bias.detach, emb.continuous_embedding.bias))
     off_table = pk.add(src.tensor(emb.discrete_embedding.table, emb.discrete_embedding))
-    packed = torch.cat(pk.chunks)
-    desc = torch.tensor(pk.desc, dtype=torch.int32, device=dev).reshape(-1)
-    return {"kind": "multi", "packed": packed, "time_lins": pk.time_lins, "desc": desc, "variant": variant, "nb_branch": enc.continuous_encoder.num_blocks,
+    main, xs, desc = pk.finish()
+    return {"kind": "multi", "main": main, "xs": xs, "time_lins": pk.time_lins, "desc": desc, "variant": variant, "nb_branch": enc.continuous_encoder.num_blocks,
             "nb_fused_exec": fe.num_blocks, "use_skip": int(bool(cfg.encoder.skip_connection)),
             "off_cw": off_cw, "off_cb": off_cb, "off_table": off_table, "time_parts": pk.time_parts,
             # a generation forward evaluates ONE head (the last four particle layers are head_c.0/.2, head_d.0/.2)

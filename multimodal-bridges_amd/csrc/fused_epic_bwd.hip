@@ -45,8 +45,8 @@ struct BwdArgs {
 };
 
 __device__ __forceinline__ float gelu_grad(float z) {
-  const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
+  const float cdf = 0.5f * (1.0f + erf_f(z * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * z * z);   // exp(-z^2/2)
   return cdf + z * pdf;
 }
 __device__ __forceinline__ float lrelu_grad(float s) { return s > 0.0f ? 1.0f : 0.01f; }

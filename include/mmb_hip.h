@@ -311,8 +311,10 @@ int mmb_grad_weight_rows_multi(int OTb, int KTb, const void* probs, int n_probs,
 /* ---------------------------------------------------------------- K-E fused (generation) */
 /* Whole MultiModalEPiC forward (multimodal_epic.py:158-194 incl. embedder.py:74-80) for one jet
  * per workgroup with activations resident in registers; `packed`/`desc` come from
- * mmb_hip.fused.pack_model (weight-normed effective weights in MFMA fragment order + transposed
- * per-jet matrices).  variant 0: S3 widths (Et32 Ec16 Ed16 H64/64/128 G16/16/32); variant 1:
+ * mmb_hip.fused.pack_model (fp32 part: transposed per-jet matrices, time/global parts, biases; after it the
+ * weight-normed effective weights of the per-particle layers in MFMA fragment order, each fp32 value split exactly
+ * into three bf16 planes hi+mid+lo, [KT][2][OT][3][64 lanes][8 bf16]: the kernels form every fp32 product from
+ * six bf16 x bf16 partial products accumulated in fp32, results are fp32 results).  variant 0: S3 widths (Et32 Ec16 Ed16 H64/64/128 G16/16/32); variant 1:
  * Et16 Ec8 Ed8 H32/32/64 G8/8/16.  N <= 128, Dc = 3, V = 8.  temb: (B,Et) with row stride
  * temb_stride (0 = one row shared by all jets).  which: 0 continuous head, 1 discrete head, 2 both. */
 int mmb_fused_epic_forward(int variant, int B, int N, const float* packed, const int32_t* desc,

@@ -1,6 +1,6 @@
 // Building blocks of the fused per-jet EPiC kernels (fused_epic.hip: forward / generation,
-// fused_epic_bwd.hip: training backward): register-resident transposed activations in the C/D layout of
-// v_mfma_f32_32x32x2_f32, packed A-operand weight fragments fetched with buffer loads, per-jet
+// fused_epic_bwd.hip: training backward): register-resident transposed activations in the 32x32 C/D layout of
+// the MFMAs, fp32 GEMMs as six bf16-plane products (mma_x), packed A-operand weight fragments fetched with buffer loads, per-jet
 // matvecs, butterfly pooling, and the row-major save/load slots of the training path.
 #pragma once
 #include "common.h"
@@ -70,7 +70,7 @@ __device__ __forceinline__ float act_f(float x) {
 
 // per-layer descriptor: offsets (in floats) into the packed parameter buffer, -1 = absent
 struct LDesc {
-  int wx;   // MFMA part, packed [KT][4][OT][64][4]        (per-particle layers)
+  int wx;   // MFMA part, packed [KT][2][OT][3 planes][64][8 bf16]  (per-particle layers; see mma_x)
   int wt;   // transposed [Kt][O]: time part (per-particle layers) or the whole W^T (per-jet layers)
   int wg;   // transposed [G][O]: global-vector part
   int b;    // bias [O] (padded to a multiple of 32 for per-particle layers)

@@ -5,12 +5,13 @@
 //
 // Layout (gfx950, wave64).  One 256-thread workgroup = one jet of N <= 128 particles; wave w owns
 // particles [32w, 32w+32).  Activations are kept TRANSPOSED (features x particles) in the C/D
-// layout of v_mfma_f32_32x32x2_f32: a 32-feature tile is one f32x16 per lane, lane&31 = particle,
+// layout of the 32x32 MFMAs: a 32-feature tile is one f32x16 per lane, lane&31 = particle,
 // register r / lane half h = feature (r&3) + 8(r>>2) + 4h.  A layer Y^T = W X^T then needs NO data
-// movement between layers: register r of an input tile IS the B operand of k-step r (its two lane
-// halves carry the two k values of the step), and the A operand is the weight fragment
-// W[o][k(r,h)], pre-packed on the host so that one dwordx4 per lane feeds four k-steps and a wave
-// reads 1 KiB contiguous.  Per-jet inputs of a layer (time embedding x mask, global vector, bias)
+// movement between layers: registers 8j..8j+7 of an input tile ARE the B operand of one 16-deep k-block
+// of v_mfma_f32_32x32x16_bf16 (after the exact three-plane bf16 split of fused_common.h: mma_x, which
+// forms every fp32 product from six bf16 partial products), and the A operand is the weight fragment,
+// pre-split and pre-packed on the host so that three dwordx4 per lane feed the block and a wave
+// reads 3 KiB contiguous.  Per-jet inputs of a layer (time embedding x mask, global vector, bias)
 // are NOT run through the MFMA: they are a per-jet matvec c,d done once per layer by the 256
 // threads and enter as the accumulator's initial value  m[p]*c[o] + d[o]  (25 % fewer MFMA flops
 // than the concatenated formulation, same result up to fp32 summation order).

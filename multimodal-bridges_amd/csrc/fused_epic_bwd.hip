@@ -1,6 +1,6 @@
 // K-E fused, training backward: the reverse pass of the whole MultiModalEPiC for one jet inside one
 // workgroup.  Mirror of fused_epic.hip's forward_jet: gradients of activations stay TRANSPOSED in the
-// C/D layout of v_mfma_f32_32x32x2_f32 (lane&31 = particle), so dX^T = W^T dZ^T is the same MFMA stream
+// 32x32 MFMA C/D layout (lane&31 = particle), so dX^T = W^T dZ^T is the same MFMA stream
 // as the forward with the transposed weight pre-packed in fragment order, and nothing but the per-layer
 // dZ (row-major, what the weight-gradient kernel streams) and the per-jet column sums of dZ (the
 // gradients of the broadcast time / global-vector inputs) ever goes to HBM.  Saved activations come

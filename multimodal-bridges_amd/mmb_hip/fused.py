@@ -3,9 +3,11 @@ parameter packing into MFMA-fragment order, and the launch wrappers.
 
 Packing (per weight-normed Linear, effective weight W = g*v/||v|| from the HIP weight-norm
 kernel):
-  x-part  W[:, x-columns]  -> zero-padded to (32*OT, 32*KT) and laid out [KT][4][OT][64][4]:
-          element (ft, q, ot, lane=(hk,i), e) = W[32ot+i][32ft + 8q + 4hk + e], i.e. exactly the
-          four consecutive k values lane (i,hk) feeds to k-steps 4q..4q+3 of input tile ft
+  x-part  W[:, x-columns]  -> zero-padded to (32*OT, 32*KT), cut into fragments (ft, jj, ot) of 16 k-values x 32
+          outputs in the A-operand order of v_mfma_f32_32x32x16_bf16 (_Packer.pack_x), each value split exactly into
+          three bf16 planes hi + mid + lo (split_planes): [KT][2][OT][3 planes][64 lanes][8 bf16] = 3 KiB per
+          fragment, stored after the fp32 part of the buffer (the kernels add the six significant partial
+          products in fp32: csrc/fused_common.h, mma_x)
   t-part / g-part / per-jet matrices -> transposed [K][O] so the matvec threads read coalesced
   bias    -> zero-padded to a multiple of 32
 Every chunk starts on a 16-byte boundary.  The layer order is the order the kernel walks.

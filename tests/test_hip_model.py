@@ -459,3 +459,39 @@ def test_generation_after_parameter_update(golden, name):
     assert torch.equal(got.discrete, want.discrete)
     if multi:
         assert torch.equal(got.continuous, want.continuous)
+
+
+@pytest.mark.parametrize("name", MODEL_GOLDENS)
+def test_fused_forward_is_fp32_accurate(golden, name):
+    """The fused kernels form every fp32 product from six bf16 partial products of an exact three-plane split
+    (DESIGN §2).  Measured against the oracle evaluated in FLOAT64 on the same parameters and inputs, their error
+    must be of the size of the fp32-MFMA layered kernels' own (both are fp32 results with different summation
+    orders) -- a bf16 or truncated-plane GEMM would be 100-1000x off this bar."""
+    from tensorclass import TensorMultiModal
+    from oracle import encoder as OE
+    g = golden(name)
+    model = build(g)
+    if model._fused_pack() is None:
+        pytest.skip("architecture not served by the fused kernels")
+    t = g.t
+    c = lambda a: None if a is None else a.cuda()
+    state = TensorMultiModal(c(t["time"]), c(t.get("xt")), c(t["kt"]), c(t["mask"]))
+    p64 = {k: (v.double() if v.is_floating_point() else v) for k, v in g.params.items()}
+    d = lambda a: None if a is None else a.double()
+    ref_c, ref_d = OE.forward(p64, d(t["time"]), d(t.get("xt")), t["kt"], t["mask"],
+                              encoder_name=g.cfg["encoder"]["name"], skip=g.cfg["encoder"].get("skip_connection", True))
+    errs = {}
+    for fused in (True, False):
+        model.use_fused = fused
+        h = model(state, None)
+        e = 0.0
+        for got, ref in ((h.continuous, ref_c), (h.discrete, ref_d)):
+            if ref is not None:
+                scale = ref.abs().max().item()
+                e = max(e, ((got.detach().cpu().double() - ref).abs().max().item()) / scale)
+        errs[fused] = e
+    # the reference's own fp32 CPU goldens sit 1.5e-6 .. 4.5e-6 from the float64 evaluation (fp32 roundings over
+    # ~20 layers); bf16 operands would give ~1e-3
+    print(name, "max error / max |head| vs float64: fused %.3g, layered %.3g" % (errs[True], errs[False]))
+    assert errs[True] < 1e-5, errs
+    assert errs[True] <= 3 * errs[False] + 5e-7, errs

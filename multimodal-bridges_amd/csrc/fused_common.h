@@ -154,8 +154,12 @@ struct Train {
   // HT tiles in C/D layout -> rows [b*N, b*N+N) of the slot; lanes of padded particles (p >= N) fall
   // outside the buffer range and the hardware drops their stores
   template <int HT>
-  __device__ __forceinline__ void tiles(const f32x16 (&x)[HT], int half) {
-    const SaveSlot s = next();
+  __device__ __forceinline__ void tiles(const f32x16 (&x)[HT], int half) { tiles_to<HT>(next(), x, half); }
+  // ... into a slot taken earlier with next(): the stores can then be issued AFTER the GEMM that consumes the tiles
+  // (vmcnt counts loads and stores in one order on gfx9: a store issued just before a GEMM makes every weight
+  // fragment load of that GEMM wait for the store's acknowledgement)
+  template <int HT>
+  __device__ __forceinline__ void tiles_to(const SaveSlot& s, const f32x16 (&x)[HT], int half) {
     const int64_t base = (int64_t)b * N * s.ld;
     int64_t room = s.n - base, want = (int64_t)N * s.ld;
     room = room < want ? room : want;

@@ -120,8 +120,8 @@ struct Epic {
     mma_x<HT, HT>(lh, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, R, l1.wx, lane, pre1);
     if constexpr (TR::on) tr.bits(sign_bits<HT>(lh), tid);
     act_tiles<HT, MMB_ACT_LRELU>(lh);
+    if constexpr (HT > 2) mma_prefetch(pre2, R, l2.wx, lane);    // before the stores: vmcnt is one in-order counter
     if constexpr (TR::on) tr.template tiles<HT>(lh, half);
-    if constexpr (HT > 2) mma_prefetch(pre2, R, l2.wx, lane);
     FE_PROF(L, PF_LOC1);
     // x <- (x + b2) + W2 lh : the residual rides in the accumulator, x's registers ARE the accumulator
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;

@@ -129,6 +129,8 @@ struct EpicB {
     // ---- l_out = drop(lrelu(y1)) + skip ;  y1 = x + W2 lh + b2
     const uint64_t sgn_y1 = sl.bits(tid);
     const Rows r_dz2 = sl.rows();
+    const uint64_t sgn_lh = sl.bits(tid);                  // (both sign words before any store of this layer)
+    const Rows r_dz1 = sl.rows();
     uint64_t keep = 0;
     if (dr) keep = dropout_keep_bits<HT>(drop_p, seed, off_l, (uint64_t)sl.b * sl.N + sl.p, half);
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
@@ -142,22 +144,21 @@ struct EpicB {
         constexpr int bit = 16 * (t & 1) + r;
         float g = dx[t][r];
         if (dr) g = ((kw >> bit) & 1u) ? g / (1.0f - drop_p) : 0.0f;
-        dx[t][r] = ((sw >> bit) & 1u) ? g : 0.01f * g; });
-      store_tile(r_dz2, t, dx[t]); });
-    // ---- d lh = W2^T d y1 ; lh = lrelu(z1)
+        dx[t][r] = ((sw >> bit) & 1u) ? g : 0.01f * g; }); });
+    // ---- d lh = W2^T d y1 ; lh = lrelu(z1).  The dZ tiles are stored AFTER the GEMM that consumes them: vmcnt counts
+    // loads and stores in one order, so a store issued before a GEMM holds up every weight fragment of that GEMM
     f32x16 dlh[HT];
     zero_tiles<HT>(dlh);
     mma_go<HT, HT>(dlh, [&](auto fc) -> const f32x16& { return dx[decltype(fc)::v]; }, P, l2.a, lane);
-    const uint64_t sgn_lh = sl.bits(tid);
-    const Rows r_dz1 = sl.rows();
+    ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v; store_tile(r_dz2, t, dx[t]); });
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
       const uint32_t sw = (uint32_t)(sgn_lh >> (32 * (t >> 1)));
       ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v;
-        if (!((sw >> (16 * (t & 1) + r)) & 1u)) dlh[t][r] *= 0.01f; });
-      store_tile(r_dz1, t, dlh[t]); });
+        if (!((sw >> (16 * (t & 1) + r)) & 1u)) dlh[t][r] *= 0.01f; }); });
     colsum<HT>(dlh, LB, sl, tid);
     // d x = d y1 (residual) + Wx1^T d z1
     mma_go<HT, HT>(dx, [&](auto fc) -> const f32x16& { return dlh[decltype(fc)::v]; }, P, l1.a, lane);
+    ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v; store_tile(r_dz1, t, dlh[t]); });
     auto sv = [&](int k) { return LB.svec[k]; };
     WaveMV<H, ET>::template run<MMB_ACT_NONE>(P + l1.b, nullptr, sv, LB.dtemb, LB.dtemb, tid);
     WaveMV<H, G>::template run<MMB_ACT_NONE>(P + l1.c, nullptr, sv, LB.dgnew, nullptr, tid);

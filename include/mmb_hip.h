@@ -306,6 +306,14 @@ int mmb_grad_weight_smallk(int M, const float* X, int64_t x_ld, int K, const flo
  *   K, Nout, leading dimensions multiples of 4, 16-byte aligned operands). */
 int mmb_weight_norm_multi(int n_rows, const void* rows, void* stream);
 int mmb_weight_norm_bwd_multi(int n_rows, const void* rows, void* stream);
+/* Parameter block of the fused entry points (`packed` / `packed_bwd` below) from the flat effective-weight buffer
+ * that mmb_weight_norm_multi writes, one launch per block after every optimizer step (the reference re-normalises
+ * inside each Linear.forward, epic.py:67,132-141): dst[i] = flat[gather[i]] (+ flat[gather2[i]] when gather2 is not
+ * NULL) for i < n_main, then n_x operand values flat[gather_x[j]] each split exactly into three bf16 planes and
+ * stored [fragment j/512][plane][j%512] after the fp32 part.  n_main % 4 == 0, n_x % 512 == 0, dst 16-byte aligned
+ * and n_main + 3 n_x / 2 floats long. */
+int mmb_pack_params(const float* flat, const int64_t* gather, const int64_t* gather2, int64_t n_main,
+                    const int64_t* gather_x, int64_t n_x, float* dst, void* stream);
 int mmb_grad_weight_rows_multi(int OTb, int KTb, const void* probs, int n_probs, int total_blocks, void* stream);
 
 /* ---------------------------------------------------------------- K-E fused (generation) */

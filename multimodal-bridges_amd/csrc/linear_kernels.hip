@@ -622,6 +622,58 @@ extern "C" int mmb_weight_norm_multi(int n_rows, const void* rows, void* stream)
   return check_launch("mmb_weight_norm_multi");
 }
 
+// Parameter block of the fused kernels from the flat effective-weight buffer, one launch: the fp32 part is a gather
+// (+ a second gather for the layers that see the time embedding twice), the MFMA operand part a gather followed by
+// the exact three-plane bf16 split of fused_common.h (mma_x): fragment f of 512 values -> [f][plane][512] bf16.
+__global__ __launch_bounds__(256) void pack_params_kernel(const float* __restrict__ flat, const int64_t* __restrict__ g1,
+                                                          const int64_t* __restrict__ g2, int64_t n_main,
+                                                          const int64_t* __restrict__ gx, int64_t n_x,
+                                                          float* __restrict__ dst) {
+  const int64_t n_main4 = n_main >> 2, n_x8 = n_x >> 3;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_main4) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = flat[g1[4 * i + e]];
+      if (g2) v[e] += flat[g2[4 * i + e]];
+    }
+    reinterpret_cast<float4*>(dst)[i] = make_float4(v[0], v[1], v[2], v[3]);
+  } else if (i - n_main4 < n_x8) {
+    const int64_t j = (i - n_main4) * 8, f = j >> 9, e0 = j & 511;
+    uint32_t pl[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = flat[gx[j + 2 * e]], b = flat[gx[j + 2 * e + 1]];
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      auto pk = [](float x, float y) { const bf16x2_t t = {(__bf16)x, (__bf16)y}; return __builtin_bit_cast(uint32_t, t); };
+      const uint32_t h = pk(a, b);
+      const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xFFFF0000u);
+      const uint32_t m = pk(ra, rb);
+      const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xFFFF0000u);
+      pl[0][e] = h;
+      pl[1][e] = m;
+      pl[2][e] = pk(sa, sb);
+    }
+    uint16_t* out = reinterpret_cast<uint16_t*>(dst + n_main);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      *reinterpret_cast<uint4*>(out + (f * 3 + q) * 512 + e0) = make_uint4(pl[q][0], pl[q][1], pl[q][2], pl[q][3]);
+  }
+}
+
+extern "C" int mmb_pack_params(const float* flat, const int64_t* gather, const int64_t* gather2, int64_t n_main,
+                               const int64_t* gather_x, int64_t n_x, float* dst, void* stream) {
+  MMB_REQUIRE(flat && gather && gather_x && dst, "mmb_pack_params: null pointer");
+  MMB_REQUIRE(n_main >= 0 && n_main % 4 == 0, "mmb_pack_params: the fp32 part must be a multiple of 4 floats");
+  MMB_REQUIRE(n_x > 0 && n_x % 512 == 0, "mmb_pack_params: the operand part is whole fragments of 512 values");
+  MMB_REQUIRE((reinterpret_cast<uintptr_t>(dst) & 15) == 0, "mmb_pack_params: dst must be 16-byte aligned");
+  const int64_t threads = n_main / 4 + n_x / 8;
+  hipLaunchKernelGGL(pack_params_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), flat,
+                     gather, gather2, n_main, gather_x, n_x, dst);
+  return check_launch("mmb_pack_params");
+}
+
 extern "C" int mmb_weight_norm_bwd_multi(int n_rows, const void* rows, void* stream) {
   MMB_REQUIRE(n_rows > 0 && rows, "mmb_weight_norm_bwd_multi: empty table");
   hipLaunchKernelGGL(weight_norm_bwd_multi_kernel, dim3(n_rows), dim3(64), 0, as_stream(stream), n_rows,

@@ -352,6 +352,12 @@ def split_planes(xs):
 
 
 def _fill_packed(dst, n_main, flat, gather, gather2, gather_x):
+    """dst <- the parameter block for the values now in `flat`: one launch (mmb_pack_params).  The torch lines below
+    are the same arithmetic for host tensors: only the CPU tests of the index maps get there."""
+    if dst.is_cuda:
+        call("mmb_pack_params", f32(flat, "flat"), i64(gather, "gather"), i64(gather2, "gather2"), n_main,
+             i64(gather_x, "gather_x"), gather_x.numel(), f32(dst, "dst"), stream())
+        return
     torch.index_select(flat, 0, gather, out=dst[:n_main])
     if gather2 is not None:
         dst[:n_main].add_(flat.index_select(0, gather2))
@@ -493,8 +499,7 @@ def repack(pack, version):
     pack.pop("grid_key", None)                               # cached time-grid tables were built from the old weights
     pack.pop("grid", None)
     _fill_packed(pack["packed"], pack["n_main"], flat, pack["gather"], pack["gather2"], pack["gather_x"])
-    pack["time_parts"] = [(l.weight()[:, :n_t] + l.weight()[:, n_t:2 * n_t]) if twice else l.weight()[:, :n_t]
-                          for l, n_t, twice in pack["time_lins"]]
+    pack["time_parts"] = None                                # rebuilt by the next generation (time_vector_table)
     return pack
 
 
@@ -546,11 +551,20 @@ def _pack_multi(model, variant, src):
             "mfma_flops_per_forward": sum(pk.mfma_flops) - sum(pk.mfma_flops[-2:])}
 
 
+def time_parts(pack):
+    """W[:, time columns] of every layer that consumes the time embedding (kernel order) for the current weights;
+    dropped by repack() and rebuilt here, because a training step repacks without ever needing them"""
+    if pack["time_parts"] is None:
+        pack["time_parts"] = [(l.weight()[:, :n_t] + l.weight()[:, n_t:2 * n_t]) if twice else l.weight()[:, :n_t]
+                              for l, n_t, twice in pack["time_lins"]]
+    return pack["time_parts"]
+
+
 def time_vector_table(pack, temb_steps):
     """(steps, n_ctab, 128): c = W_t temb for every time-consuming layer at every grid point."""
     from . import ops
     steps = temb_steps.shape[0]
-    parts = pack["time_parts"]
+    parts = time_parts(pack)
     tab = torch.zeros(steps, len(parts), 128, dtype=torch.float32, device=temb_steps.device)
     for i, Wt in enumerate(parts):
         ops.linear_cat([(temb_steps, ops.SEG_ROW)], Wt, None, 1, out=tab[:, i, :Wt.shape[0]])

@@ -490,3 +490,22 @@ def test_grad_weight_smallk(ops, M, K, Nout):
     want = dZ.double().t() @ X.double()
     close(dW.double() - 0.5, want, rtol=1e-4, atol=2e-5 * float(want.abs().max()))
     close(db.double() + 2.0, dZ.double().sum(0), rtol=1e-4, atol=2e-5 * float(dZ.abs().sum(0).max()))
+
+
+def test_pack_params_matches_torch_split():
+    """mmb_pack_params (one launch: gathers + exact three-plane bf16 split) against the torch restatement, bit for bit"""
+    from mmb_hip import fused
+    g = torch.Generator().manual_seed(5)
+    n_flat, n_main, F = 5000, 1236, 7
+    flat = torch.randn(n_flat + 1, generator=g) * 10.0 ** torch.empty(n_flat + 1).uniform_(-4, 3, generator=g)
+    flat[-1] = 0.0
+    gather = torch.randint(0, n_flat + 1, (n_main,), generator=g)
+    gather2 = torch.where(torch.rand(n_main, generator=g) < 0.3, torch.randint(0, n_flat, (n_main,), generator=g),
+                          torch.full((n_main,), n_flat))
+    gather_x = torch.randint(0, n_flat + 1, (F * 512,), generator=g)
+    for g2 in (gather2, None):
+        want = torch.empty(n_main + F * 768)
+        fused._fill_packed(want, n_main, flat, gather, g2, gather_x)                    # host tensors: torch lines
+        got = torch.zeros(n_main + F * 768, device="cuda")
+        fused._fill_packed(got, n_main, flat.cuda(), gather.cuda(), None if g2 is None else g2.cuda(), gather_x.cuda())
+        assert torch.equal(got.cpu().view(torch.int32), want.view(torch.int32))

@@ -13,8 +13,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # kernel 168 -> 144 B/lane of scratch, S2 112 -> 68, training forward 392 -> 316) and measured +2..5 % on every bench
 # line
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-mllvm", "-amdgpu-sched-strategy=max-memory-clause",
-         ] + os.environ.get("MMB_EXTRA_FLAGS", "").split()
+         "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+SCHED = os.environ.get("MMB_SCHED", "max-memory-clause")                       # developer A/B: MMB_SCHED=default
+if SCHED != "default":
+    FLAGS += ["-mllvm", "-amdgpu-sched-strategy=" + SCHED]
+FLAGS += os.environ.get("MMB_EXTRA_FLAGS", "").split()
 
 
 def sources():

@@ -1,7 +1,8 @@
 """Oracle: embedder + EPiC set encoders (test infrastructure; see oracle/__init__.py).
 
-Functional restatement of encoders/embedder.py, encoders/epic.py and
-encoders/multimodal_epic.py.  Parameters come as a flat dict {reference parameter
+Functional restatement of encoders/embedder.py, encoders/epic.py,
+encoders/multimodal_epic.py and encoders/particle_transformer.py:8-167 (whose layers are torch's
+nn.TransformerEncoderLayer: third-party arithmetic, restated from its documented definition).  Parameters come as a flat dict {reference parameter
 name: tensor} (the reference's state_dict naming); the network
 structure (projection or not, how many layers exist, how many are executed) is read
 off the parameter names, so no config object is needed.  Dropout is not modelled
@@ -159,11 +160,85 @@ def unimodal_epic(p, loc_time, loc_cont, loc_disc, glob_time, mask, skip=True, p
     return h
 
 
-def forward(p, time, continuous, discrete, mask, encoder_name="MultiModalEPiC", skip=True):
+# ------------------------------------------------------------------ transformer set encoder --
+def layer_norm(x, w, b, eps=1e-5):
+    """nn.LayerNorm over the last dim (biased variance, eps inside the sqrt)."""
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def attention(q, k, v, key_ignored):
+    """Scaled dot-product attention per head with a key-padding mask (True = key ignored).
+    q,k,v (B,nh,N,dh).  A query whose keys are ALL ignored gets zeros (torch >= 2.5 'safe softmax',
+    what nn.MultiheadAttention's need_weights=False path gives)."""
+    dh = q.shape[-1]
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    s = s.masked_fill(key_ignored[:, None, None, :], float("-inf"))
+    m = s.max(-1, keepdim=True)[0]
+    m = torch.where(torch.isinf(m), torch.zeros_like(m), m)
+    e = torch.exp(s - m)
+    den = e.sum(-1, keepdim=True)
+    a = torch.where(den > 0, e / den.clamp(min=1e-38), torch.zeros_like(e))
+    return a @ v
+
+
+def transformer_layer(p, prefix, h, key_ignored, nheads):
+    """nn.TransformerEncoderLayer(batch_first, post-LN, ReLU FFN) as built at particle_transformer.py:29-35,
+    dropout not modelled."""
+    B, N, D = h.shape
+    dh = D // nheads
+    qkv = F.linear(h, p[prefix + ".self_attn.in_proj_weight"], p[prefix + ".self_attn.in_proj_bias"])
+    q, k, v = [z.reshape(B, N, nheads, dh).transpose(1, 2) for z in qkv.chunk(3, dim=-1)]
+    a = attention(q, k, v, key_ignored).transpose(1, 2).reshape(B, N, D)
+    a = F.linear(a, p[prefix + ".self_attn.out_proj.weight"], p[prefix + ".self_attn.out_proj.bias"])
+    h = layer_norm(h + a, p[prefix + ".norm1.weight"], p[prefix + ".norm1.bias"])
+    f = F.linear(F.relu(F.linear(h, p[prefix + ".linear1.weight"], p[prefix + ".linear1.bias"])),
+                 p[prefix + ".linear2.weight"], p[prefix + ".linear2.bias"])
+    return layer_norm(h + f, p[prefix + ".norm2.weight"], p[prefix + ".norm2.bias"])
+
+
+def transformer_block(p, prefix, t_loc, x, mask, nheads):
+    """TransformerEncoderBlock.forward, particle_transformer.py:38-50: input projection + (projected)
+    per-particle time embedding, then the encoder layers with src_key_padding_mask = mask > 0 --
+    the REAL particles are the ignored keys (Q4), every slot attends to the padded slots only."""
+    h = F.linear(x.float(), p[prefix + ".input_proj.weight"], p[prefix + ".input_proj.bias"])
+    if prefix + ".time_proj.weight" in p:
+        h = h + F.linear(t_loc, p[prefix + ".time_proj.weight"], p[prefix + ".time_proj.bias"])
+    else:
+        h = h + t_loc
+    ignored = mask.squeeze(-1) > 0
+    i = 0
+    while f"{prefix}.transformer.layers.{i}.linear1.weight" in p:
+        h = transformer_layer(p, f"{prefix}.transformer.layers.{i}", h, ignored, nheads)
+        i += 1
+    return h
+
+
+def multimodal_transformer(p, loc_time, loc_cont, loc_disc, mask, nheads, prefix="encoder"):
+    """MultiModalParticleTransformer.forward, particle_transformer.py:139-167 (head input order is
+    cat[t, h_i, f_i], unlike the EPiC heads)."""
+    t = loc_time
+    h1 = transformer_block(p, prefix + ".continuous_encoder", t, loc_cont, mask, nheads)
+    h2 = transformer_block(p, prefix + ".discrete_encoder", t, loc_disc, mask, nheads)
+    if any(k.startswith(prefix + ".fused_encoder.") for k in p):
+        f = transformer_block(p, prefix + ".fused_encoder", t, torch.cat([h1, h2], dim=-1), mask, nheads)
+        f1, f2 = torch.chunk(f, 2, dim=-1)
+        hc = _head(p, prefix + ".continuous_head", torch.cat([t, h1, f1], dim=-1))
+        hd = _head(p, prefix + ".discrete_head", torch.cat([t, h2, f2], dim=-1))
+    else:
+        hc = _head(p, prefix + ".continuous_head", torch.cat([t, h1], dim=-1))
+        hd = _head(p, prefix + ".discrete_head", torch.cat([t, h2], dim=-1))
+    return hc, hd
+
+
+def forward(p, time, continuous, discrete, mask, encoder_name="MultiModalEPiC", skip=True, num_heads=None):
     """multimodal_bridge_matching.py:73-75 -> (head_continuous | None, head_discrete | None)."""
     lt, lc, ld, gt = embedder(p, time, continuous, discrete, mask)
     if encoder_name == "MultiModalEPiC":
         return multimodal_epic(p, lt, lc, ld, gt, mask, skip)
+    if encoder_name == "MultiModalParticleTransformer":
+        return multimodal_transformer(p, lt, lc, ld, mask, num_heads)
     if encoder_name == "UniModalEPiC":
         h = unimodal_epic(p, lt, lc, ld, gt, mask, skip)
         if discrete is not None and continuous is None:

@@ -67,7 +67,7 @@ def training_step(p, cfg, target, source, noise):
     """multimodal_bridge_matching.py:77-94 -> (loss, loss_c, loss_d, state)."""
     st = sample_bridges(cfg, target, source, noise)
     hc, hd = E_.forward(p, st["time"], st["continuous"], st["discrete"], st["mask"],
-                        cfg["encoder_name"], cfg.get("skip_connection", True))
+                        cfg["encoder_name"], cfg.get("skip_connection", True), cfg.get("num_heads"))
     tgt = drift_target(cfg, st, source, target) if hc is not None else None
     lc, ld = loss_fn(hc, hd, tgt, target.get("discrete"), st["mask"], cfg.get("vocab_freq"))
     loss = multimode_loss([lc, ld], cfg.get("loss_weights", "fixed"), p.get("loss_multimode.loss_weights"))
@@ -106,7 +106,7 @@ def simulate_dynamics(p, cfg, source, noise=None, max_steps=None):
             break
         time = torch.full((Bn, 1), tv.item())
         if x is not None:
-            hc, _ = E_.forward(p, time, x, k, mask, name, skip)
+            hc, _ = E_.forward(p, time, x, k, mask, name, skip, cfg.get("num_heads"))
             if cfg["solver_continuous"] == "euler":
                 x = S_.euler_step(x, hc, dt)
             else:
@@ -114,7 +114,7 @@ def simulate_dynamics(p, cfg, source, noise=None, max_steps=None):
                 dw = noise["delta_w"][i] if "delta_w" in noise else torch.randn_like(x)   # solvers.py:31
                 x = S_.euler_maruyama_step(x, hc, dt, sig, dw)
         if k is not None:
-            _, hd = E_.forward(p, time, x, k, mask, name, skip)
+            _, hd = E_.forward(p, time, x, k, mask, name, skip, cfg.get("num_heads"))
             rates = B_.telegraph_rate(time, k, hd, cfg["gamma"], V, cfg["thermostat_fn"])
             if cfg["solver_discrete"] == "tauleap":
                 dn = noise["delta_n"][i] if "delta_n" in noise else torch.poisson(rates * dt)  # solvers.py:64

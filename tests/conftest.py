@@ -53,6 +53,26 @@ class Golden:
     def grads(self):
         return {k[5:]: v for k, v in self.t.items() if k.startswith("grad:")}
 
+    def grad_summaries(self):
+        """{name: (norm, projection on the deterministic probe vector)} for EVERY parameter (paper-size fixtures)."""
+        return {k[5:]: v for k, v in self.t.items() if k.startswith("gsum:")}
+
+    def check_grad_summaries(self, grad_of, rtol, atol_scale):
+        """grad_of(name) -> gradient tensor | None.  Compares norm and probe projection of every parameter."""
+        from oracle.synth import synth_param
+        bad = []
+        gmax = max(float(v[0]) for v in self.grad_summaries().values())
+        for n, ref in self.grad_summaries().items():
+            gr = grad_of(n)
+            gr = torch.zeros(self.params[n].shape) if gr is None else gr.detach().cpu()
+            probe = synth_param(n + "#probe", gr.shape, 99).double()
+            got = (float(gr.double().norm()), float((gr.double() * probe).sum()))
+            tol = rtol * float(ref[0]) + atol_scale * gmax
+            # the projection of a length-n vector on a unit-variance probe has the scale of the norm
+            if abs(got[0] - float(ref[0])) > tol or abs(got[1] - float(ref[1])) > tol * max(1.0, probe.norm().item() / max(gr.numel(), 1) ** 0.5):
+                bad.append((n, got, (float(ref[0]), float(ref[1]))))
+        assert not bad, f"{self.name}: gradient summaries differ: {bad[:4]} ({len(bad)} parameters)"
+
 
 @pytest.fixture(scope="session")
 def golden():
@@ -66,4 +86,7 @@ def golden():
     return get
 
 
-MODEL_GOLDENS = ["mm_tiny", "mm_tiny_masked", "mm_mid", "mm_odd", "uni_tiny", "uni_mid", "S3", "S2"]
+MODEL_GOLDENS = ["mm_tiny", "mm_tiny_masked", "mm_mid", "mm_odd", "uni_tiny", "uni_mid", "S3", "S2",
+                 "tr_tiny", "tr_odd", "S4"]
+EPIC_GOLDENS = [n for n in MODEL_GOLDENS if not (n.startswith("tr_") or n == "S4")]
+TRANSFORMER_GOLDENS = ["tr_tiny", "tr_odd", "S4"]

@@ -160,6 +160,25 @@ def variants():
     c["data"].update(max_num_particles=128)
     c["encoder"].update(num_blocks=10, dim_hidden_local=128, dim_hidden_glob=16, dim_emb_time=128, dim_emb_discrete=128)
     v["S2"] = c
+    # transformer set encoder (particle_transformer.py:52-167)
+    c = base_cfg()
+    c["encoder"].update(name="MultiModalParticleTransformer", num_blocks=[2, 1, 2], dim_hidden_local=[8, 8, 16],
+                        num_heads=2, dim_emb_time=8, dim_emb_continuous=4, dim_emb_discrete=4)
+    c["encoder"].pop("dim_hidden_glob")
+    v["tr_tiny"] = c
+    c = base_cfg()                     # no fusion stage, time width != model width (time_proj is a Linear), head dim 6/4
+    c["encoder"].update(name="MultiModalParticleTransformer", num_blocks=[1, 2, 0], dim_hidden_local=[12, 8, 0],
+                        num_heads=2, dim_emb_time=6, dim_emb_continuous=5, dim_emb_discrete=7)
+    c["encoder"].pop("dim_hidden_glob")
+    c["model"].update(loss_weights="learnable")
+    v["tr_odd"] = c
+    c = base_cfg()                     # SURVEY 8d S4 widths
+    c["data"].update(max_num_particles=150)
+    c["encoder"].update(name="MultiModalParticleTransformer", num_blocks=[2, 2, 2], dim_hidden_local=[64, 64, 128],
+                        num_heads=4, dim_emb_time=64, dim_emb_continuous=64, dim_emb_discrete=64)
+    c["encoder"].pop("dim_hidden_glob")
+    c["model"].update(loss_weights="learnable")
+    v["S4"] = c
     return v
 
 
@@ -172,6 +191,7 @@ def flat_cfg(cfg):
     d["modality"] = cfg["data"]["modality"]
     d["encoder_name"] = cfg["encoder"]["name"]
     d["skip_connection"] = cfg["encoder"]["skip_connection"]
+    d["num_heads"] = cfg["encoder"].get("num_heads")
     return d
 
 
@@ -202,6 +222,11 @@ def make_mask(B, N, kind, g):
     if kind == "ones":
         return torch.ones(B, N, 1, dtype=torch.int64)
     n = torch.randint(1, N + 1, (B,), generator=g)
+    if kind == "random_full":             # jet 0 full (Q4: every key ignored), jet 1 with ONE padded slot
+        n[0], n[1] = N, N - 1
+    if kind == "random_notfull":          # every jet keeps a padded slot, jet 0 exactly one
+        n = n.clamp(max=N - 1)
+        n[0] = N - 1
     r = torch.rand(B, N, generator=g)
     rank = r.argsort(1).argsort(1)
     return (rank < n[:, None]).long().unsqueeze(-1)
@@ -278,7 +303,8 @@ def golden_solvers():
     g = torch.Generator().manual_seed(12)
     B, N, V = 6, 16, 8
     out = {}
-    for kind, gamma in (("ConstantThermostat", 0.125), ("ConstantThermostat", 0.075), ("InverseSquareThermostat", 0.125)):
+    for kind, gamma in (("ConstantThermostat", 0.125), ("ConstantThermostat", 0.075), ("InverseSquareThermostat", 0.125),
+                        ("InverseThermostat", 0.125)):
         tb = TelegraphBridge(gamma, V, getattr(T, kind)(gamma, V))
         t = torch.rand(B, generator=g) * 0.98 + 0.01
         t[0], t[1] = 1e-4, 0.9999
@@ -349,7 +375,9 @@ def capture_encoder(model, state, batch):
     for name, mod in model.encoder.named_modules():
         if name in ("continuous_encoder", "discrete_encoder", "fused_encoder", "epic",
                     "continuous_encoder.epic_proj", "continuous_encoder.epic_layers.0",
-                    "epic.epic_proj", "epic.epic_layers.0", "fused_encoder.epic_layers.0"):
+                    "epic.epic_proj", "epic.epic_layers.0", "fused_encoder.epic_layers.0",
+                    "continuous_encoder.transformer.layers.0", "discrete_encoder.transformer.layers.0",
+                    "fused_encoder.transformer.layers.0"):
             hooks.append(mod.register_forward_hook(hook(name)))
     loc, glob = model.embedder(state, batch)
     cap["emb.time"] = loc.time.detach().clone()
@@ -364,7 +392,7 @@ def capture_encoder(model, state, batch):
     return heads, cap
 
 
-def golden_model(name, cfg, B, N, mask_kind, store_params, seed=3, steps_list=(10,)):
+def golden_model(name, cfg, B, N, mask_kind, store_params, seed=3, steps_list=(10,), explicit_source=False):
     from tensorclass import TensorMultiModal
     from datamodules.datasets import DataCoupling
     print(f"[{name}] B={B} N={N} mask={mask_kind}")
@@ -424,15 +452,29 @@ def golden_model(name, cfg, B, N, mask_kind, store_params, seed=3, steps_list=(1
             out["grad:" + n] = gr
         else:                                     # paper-size: keep a few representative grads
             if n.endswith("output_layer.weight_g") or n.endswith("head.2.bias") or n.endswith("loss_weights") \
-                    or n.endswith("epic_layers.0.fc_glob1.weight_v") or n.endswith("time_embedding.1.bias"):
+                    or n.endswith("epic_layers.0.fc_glob1.weight_v") or n.endswith("time_embedding.1.bias") \
+                    or n.endswith("layers.1.self_attn.in_proj_bias") or n.endswith("layers.0.norm1.weight"):
                 out["grad:" + n] = gr
+            # ... and pin EVERY parameter's gradient through two scalars: its norm and its projection on a
+            # deterministic probe vector
+            probe = synth_param(n + "#probe", gr.shape, 99).double()
+            out["gsum:" + n] = np.array([float(gr.double().norm()), float((gr.double() * probe).sum())])
     out["grad_norm"] = np.float64(gnorm2 ** 0.5)
 
     # ---- generation (golden 8): predict_step under the tape
     for steps in steps_list:
         model.config.model.num_timesteps = steps
         target = TensorMultiModal(None, None if x1 is None else x1.clone(), k1.clone(), mask.clone())
-        batch = DataCoupling(TensorMultiModal(), target, None)
+        src = TensorMultiModal()
+        if explicit_source:
+            # given source (no multiplicity draw from the pmf: at N = 16 nearly every jet would be full, and under
+            # no_grad torch's fused encoder-layer path returns NaN for a jet without a padded slot -- every key is
+            # ignored, Q4 -- so the reference cannot generate such a jet at all; the training path gives zeros there)
+            gs = torch.Generator().manual_seed(4242 + seed + steps)
+            src = TensorMultiModal(None, None if x1 is None else torch.randn(B, N, 3, generator=gs),
+                                   torch.randint(0, V, (B, N, 1), generator=gs),
+                                   make_mask(B, N, "random_notfull", gs))
+        batch = DataCoupling(src, target, None)
         torch.manual_seed(777 + seed + steps)
         with Tape(V) as tape, torch.no_grad():
             paths, _ = model.predict_step(batch, 0)
@@ -470,12 +512,15 @@ def main():
     V = variants()
     golden_model("mm_tiny", V["mm_tiny"], 4, 16, "ones", True, steps_list=(10, 100))
     golden_model("mm_tiny_masked", V["mm_tiny"], 5, 8, "random", True, seed=4)
-    golden_model("mm_mid", V["mm_mid"], 4, 16, "random", True, seed=5)
+    golden_model("mm_mid", V["mm_mid"], 4, 16, "random", True, seed=5, steps_list=(10, 100))
     golden_model("mm_odd", V["mm_odd"], 3, 11, "random", True, seed=6)
     golden_model("uni_tiny", V["uni_tiny"], 4, 16, "random", True, seed=7, steps_list=(10, 100))
-    golden_model("uni_mid", V["uni_mid"], 4, 16, "random", True, seed=8)
-    golden_model("S3", V["S3"], 2, 128, "random", False, seed=9, steps_list=(5,))
-    golden_model("S2", V["S2"], 2, 128, "random", False, seed=10, steps_list=(5,))
+    golden_model("uni_mid", V["uni_mid"], 4, 16, "random", True, seed=8, steps_list=(10, 100))
+    golden_model("S3", V["S3"], 2, 128, "random", False, seed=9, steps_list=(5, 100))
+    golden_model("S2", V["S2"], 2, 128, "random", False, seed=10, steps_list=(5, 100))
+    golden_model("tr_tiny", V["tr_tiny"], 4, 16, "random_full", True, seed=11, explicit_source=True)
+    golden_model("tr_odd", V["tr_odd"], 3, 11, "random_full", True, seed=12, explicit_source=True)
+    golden_model("S4", V["S4"], 2, 150, "random_full", False, seed=13, steps_list=(5,), explicit_source=True)
 
 
 if __name__ == "__main__":

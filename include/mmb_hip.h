@@ -48,6 +48,7 @@ extern "C" {
 #define MMB_ACT_NONE 0
 #define MMB_ACT_GELU 1   /* exact erf form, nn.GELU() default  (epic.py:124) */
 #define MMB_ACT_LRELU 2  /* leaky_relu slope 0.01              (epic.py:172) */
+#define MMB_ACT_RELU 3   /* nn.TransformerEncoderLayer's FFN activation (particle_transformer.py:29-35) */
 
 /* segment kinds of a concatenated linear input (mmb_linear_cat) */
 #define MMB_SEG_ROW 0       /* (M,K_s) one row per particle                              */
@@ -315,6 +316,39 @@ int mmb_weight_norm_bwd_multi(int n_rows, const void* rows, void* stream);
 int mmb_pack_params(const float* flat, const int64_t* gather, const int64_t* gather2, int64_t n_main,
                     const int64_t* gather_x, int64_t n_x, float* dst, void* stream);
 int mmb_grad_weight_rows_multi(int OTb, int KTb, const void* probs, int n_probs, int total_blocks, void* stream);
+
+/* ---------------------------------------------------------------- transformer set encoder */
+/* TransformerEncoderBlock (encoders/particle_transformer.py:8-50) = torch's nn.TransformerEncoderLayer (post-LN,
+ * ReLU FFN, batch_first) over the particles of one jet.  The Linear layers (input/time projection, in_proj,
+ * out_proj, linear1/2, + residual) are mmb_linear_cat calls; these are the two ops it lacks.
+ *
+ * mmb_attention_fwd: multi-head scaled-dot-product self-attention per jet.  qkv (B*N, 3H) rows = [q | k | v] as
+ * nn.MultiheadAttention's in_proj packs them, head h owns columns h*H/nheads...; out (B*N, H) heads concatenated
+ * (the input of out_proj).  Keys are restricted by the mask: valid_is_zero = 1 keeps the keys whose maskf is 0 --
+ * what the reference does, src_key_padding_mask = mask > 0 (particle_transformer.py:50, quirk Q4: the REAL particles
+ * are the ignored keys) -- valid_is_zero = 0 keeps the keys with maskf != 0.  A jet with no valid key gets zeros
+ * (torch's need_weights=False path).  lse (B, nheads, N) | NULL: log-sum-exp of the scaled scores, for the backward.
+ * H/nheads <= 64 and 8*N*pad(H/nheads) + 12*N bytes <= 64 KiB of LDS. */
+int mmb_attention_fwd(int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld, const float* maskf,
+                      int valid_is_zero, float* out, int64_t out_ld, float* lse, void* stream);
+/* its reverse (autograd of F.scaled_dot_product_attention): dqkv (B*N, 3H) is OVERWRITTEN with [dq | dk | dv]
+ * (zeros for the keys that took no part) from dout = d loss / d out and the saved out, lse. */
+int mmb_attention_bwd(int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld, const float* maskf,
+                      int valid_is_zero, const float* out, int64_t out_ld, const float* dout, int64_t dout_ld,
+                      const float* lse, float* dqkv, int64_t dqkv_ld, void* stream);
+/* nn.LayerNorm over the last dim (norm1 / norm2 of the encoder layer; biased variance, eps inside the root):
+ * y = (x - mean)/sqrt(var + eps) * gamma + beta; stats (M,2) | NULL receives (mean, 1/sqrt(var+eps)) per row. */
+int mmb_layernorm_fwd(int64_t M, int D, const float* x, int64_t x_ld, const float* gamma, const float* beta, float eps,
+                      float* y, int64_t y_ld, float* stats, void* stream);
+/* its reverse: dx (overwritten, or += when accumulate) and dgamma, dbeta (ACCUMULATED with atomics: zero them
+ * first).  D <= 512. */
+int mmb_layernorm_bwd(int64_t M, int D, const float* x, int64_t x_ld, const float* gamma, const float* stats,
+                      const float* dy, int64_t dy_ld, float* dx, int64_t dx_ld, int accumulate, float* dgamma,
+                      float* dbeta, void* stream);
+/* dst[i] (+)= sum_r src[r*stride + i], i < n: folds the replicated accumulators of mmb_grad_weight_rows for the
+ * plain (not weight-normed) nn.Linear layers of the transformer (mmb_weight_norm_bwd_rep does it for the others). */
+int mmb_sum_replicas(int64_t n, int replicas, int64_t stride, const float* src, float* dst, int accumulate,
+                     void* stream);
 
 /* ---------------------------------------------------------------- K-E fused (generation) */
 /* Whole MultiModalEPiC forward (multimodal_epic.py:158-194 incl. embedder.py:74-80) for one jet

@@ -107,10 +107,12 @@ def _produced(tape):
     keys = set()
     k = GradStore._key
     for e in tape:
-        if e[0] == "linear":
+        if e[0] in ("linear", "plinear"):
             for t in (e[9], e[10]):
                 if t is not None:
                     keys.add(k(t))
+        elif e[0] in ("attn", "ln"):
+            keys.add(k(e[2]))
         elif e[0] == "pool":
             keys.add(k(e[2]))
         elif e[0] == "cat":
@@ -168,8 +170,48 @@ def param_grads(layer, segs, dZ, S, Sm, arena, touched):
     return W
 
 
+def plain_param_grads(spec, segs, dZ, S, Sm, arena):
+    """The same for a PlainLinear (encoders/particle_transformer.py): dW of the concatenated weight through the
+    row-streaming kernel, replicas folded by mmb_sum_replicas, then split over the nn.Linear parameters (an
+    identity part has none).  Returns the effective (concatenated) weight."""
+    M, Nout = dZ.shape
+    W = spec.weight()
+    R = GW_REPLICAS if M >= 16384 else 1
+    Kall = W.shape[1]
+    dWr = arena.take((R, Nout * Kall))
+    dbr = arena.take((R, Nout))
+    dW = dWr[0].view(Nout, Kall)
+    rep = dict(replicas=R, rep_stride=dWr.stride(0), db_stride=dbr.stride(0))
+    koff = 0
+    first = True
+    for t, kind in segs:
+        Ks = t.shape[1]
+        dWs = dW[:, koff:koff + Ks]
+        if kind == SEG_ROW:
+            ops.grad_weight_rows(t, dZ, dWs, dbr[0] if first else None, **rep)
+            first = False
+        elif kind == SEG_JET:
+            ops.grad_weight_rows(t, S, dWs, None)
+        else:
+            ops.grad_weight_rows(t, Sm, dWs, None)
+        koff += Ks
+    if R > 1:
+        dW = ops.sum_replicas(dWr, torch.empty(Nout * Kall, dtype=torch.float32, device=dZ.device)).view(Nout, Kall)
+        db = ops.sum_replicas(dbr, torch.empty(Nout, dtype=torch.float32, device=dZ.device))
+    else:
+        db = dbr[0]
+    koff = 0
+    for w, k in spec.parts:
+        if w is not None:
+            _acc_param(w, dW[:, koff:koff + k].contiguous() if len(spec.parts) > 1 else dW.clone())
+        koff += k
+    for i, b in enumerate(spec.biases):
+        _acc_param(b, db.clone())
+    return W
+
+
 def _linear_bwd(e, store, produced, mi, seed, arena, touched):
-    _, layer, N, segs, act, res1, post, res2, pre, y1, y2, p, off = e
+    kind_, layer, N, segs, act, res1, post, res2, pre, y1, y2, p, off = e
     gY1, gY2 = store.get(y1), store.get(y2)
     if gY1 is None and gY2 is None:
         return
@@ -189,7 +231,10 @@ def _linear_bwd(e, store, produced, mi, seed, arena, touched):
     kinds = {k for _, k in segs}
     S = ops.jet_sum(dZ, B, N) if SEG_JET in kinds else None
     Sm = ops.jet_sum(dZ, B, N, maskf=maskf) if SEG_JET_MASK in kinds else None
-    W = param_grads(layer, segs, dZ, S, Sm, arena, touched)
+    if kind_ == "plinear":
+        W = plain_param_grads(layer, segs, dZ, S, Sm, arena)
+    else:
+        W = param_grads(layer, segs, dZ, S, Sm, arena, touched)
     # ---- inputs
     need = [GradStore._key(t) in produced for t, _ in segs]
     if not any(need):
@@ -208,6 +253,29 @@ def _linear_bwd(e, store, produced, mi, seed, arena, touched):
                 red = S if kind == SEG_JET else Sm
                 ops.linear_cat([(red, SEG_ROW)], Wseg, None, 1, residual=res, out=gx)
         koff += Ks
+
+
+def _attn_bwd(e, store, mi):
+    _, qkv, a, lse, nheads = e
+    g = store.get(a)
+    if g is not None:
+        store.add(qkv, ops.attention_bwd(qkv, mi, nheads, a, g, lse, valid_is_zero=True))
+
+
+def _ln_bwd(e, store, produced, arena):
+    _, x, y, stats, norm = e
+    g = store.get(y)
+    if g is None:
+        return
+    D = x.shape[1]
+    dgamma, dbeta = arena.take((D,)), arena.take((D,))
+    if GradStore._key(x) in produced:
+        gx, fresh = store.target(x)
+    else:
+        gx, fresh = torch.empty_like(x), True
+    ops.layernorm_bwd(x, norm.weight.detach(), stats, g, gx, not fresh, dgamma, dbeta)
+    _acc_param(norm.weight, dgamma.clone())
+    _acc_param(norm.bias, dbeta.clone())
 
 
 def _embed_bwd(e, store, mi):
@@ -262,12 +330,18 @@ def run_backward(model, tape, heads, d_hc, d_hd, d_s=None, scale=None):
     mi = next(e[3] for e in tape if e[0] == "embed")
     seed = model.seed
     n_acc = sum(GW_REPLICAS * (e[1].weight_v.numel() + e[1].weight_v.shape[0] + 8) for e in tape if e[0] == "linear")
+    n_acc += sum(GW_REPLICAS * (e[1].dim_out * (e[1].K + 1) + 8) for e in tape if e[0] == "plinear")
+    n_acc += sum(2 * e[1].shape[1] + 8 for e in tape if e[0] == "ln")
     arena = Arena(n_acc, mi.maskf.device)
     touched = set()
     for e in reversed(tape):
         kind = e[0]
-        if kind == "linear":
+        if kind in ("linear", "plinear"):
             _linear_bwd(e, store, produced, mi, seed, arena, touched)
+        elif kind == "attn":
+            _attn_bwd(e, store, mi)
+        elif kind == "ln":
+            _ln_bwd(e, store, produced, arena)
         elif kind == "pool":
             gP = store.get(e[2])
             if gP is not None and GradStore._key(e[1]) in produced:

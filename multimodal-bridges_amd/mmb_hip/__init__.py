@@ -91,6 +91,15 @@ SIGNATURES = {
     "mmb_fused_uni_generate": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, c_f32p, c_i32p,
                                c_i64p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_float, C.c_int, C.c_float,
                                c_f32p, C.c_uint64, C.c_uint64, c_stream],
+    "mmb_attention_fwd": [C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, C.c_int, c_f32p, C.c_int64,
+                          c_f32p, c_stream],
+    "mmb_attention_bwd": [C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, C.c_int, c_f32p, C.c_int64,
+                          c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_stream],
+    "mmb_layernorm_fwd": [C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_float, c_f32p, C.c_int64, c_f32p,
+                          c_stream],
+    "mmb_layernorm_bwd": [C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64,
+                          C.c_int, c_f32p, c_f32p, c_stream],
+    "mmb_sum_replicas": [C.c_int64, C.c_int, C.c_int64, c_f32p, c_f32p, C.c_int, c_stream],
     "mmb_grad_weight": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
                         C.POINTER(C.c_int), c_f32p, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p, c_stream],
 }

@@ -11,7 +11,7 @@ from . import call, MMBError
 THERMOSTATS = {"ConstantThermostat": 0, "InverseThermostat": 1, "LinearThermostat": 2,
                "InverseSquareThermostat": 3, "SigmoidThermostat": 4}
 BRIDGES = {"UniformFlow": 0, "SchrodingerBridge": 1}
-ACT = {None: 0, "none": 0, "gelu": 1, "lrelu": 2}
+ACT = {None: 0, "none": 0, "gelu": 1, "lrelu": 2, "relu": 3}
 SEG_ROW, SEG_JET, SEG_JET_MASK = 0, 1, 2
 
 
@@ -517,3 +517,54 @@ def grad_weight_smallk(X, dZ, dW, db=None):
         raise MMBError("grad_weight_smallk: shape mismatch")
     call("mmb_grad_weight_smallk", X.shape[0], X.data_ptr(), X.stride(0), X.shape[1], dZ.data_ptr(), dZ.stride(0),
          dZ.shape[1], dW.data_ptr(), dW.stride(0), db.data_ptr() if db is not None else None, stream())
+
+
+# ------------------------------------------------------------------------ transformer set encoder
+def attention_fwd(qkv, mi, nheads, valid_is_zero=True, want_lse=False):
+    """qkv (B*N, 3H) [q|k|v] -> out (B*N, H) (+ lse (B, nheads, N) for the backward)."""
+    B, N = mi.B, mi.N
+    H = qkv.shape[1] // 3
+    if qkv.dim() != 2 or qkv.shape[0] != B * N or qkv.shape[1] != 3 * H or qkv.stride(1) != 1:
+        raise MMBError("attention_fwd: qkv must be (B*N, 3H) with unit inner stride")
+    f32(qkv.new_empty(0), "qkv")                              # device / dtype check
+    out = torch.empty(B * N, H, dtype=torch.float32, device=qkv.device)
+    lse = torch.empty(B, nheads, N, dtype=torch.float32, device=qkv.device) if want_lse else None
+    call("mmb_attention_fwd", B, N, H, nheads, qkv.data_ptr(), qkv.stride(0), f32(mi.maskf), int(bool(valid_is_zero)),
+         f32(out), out.stride(0), f32(lse), stream())
+    return (out, lse) if want_lse else out
+
+
+def attention_bwd(qkv, mi, nheads, out, dout, lse, valid_is_zero=True):
+    B, N = mi.B, mi.N
+    H = qkv.shape[1] // 3
+    if dout.stride(1) != 1 or out.stride(1) != 1:
+        raise MMBError("attention_bwd: unit inner stride required")
+    dqkv = torch.empty(B * N, 3 * H, dtype=torch.float32, device=qkv.device)
+    call("mmb_attention_bwd", B, N, H, nheads, qkv.data_ptr(), qkv.stride(0), f32(mi.maskf), int(bool(valid_is_zero)),
+         out.data_ptr(), out.stride(0), dout.data_ptr(), dout.stride(0), f32(lse), f32(dqkv), dqkv.stride(0), stream())
+    return dqkv
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, want_stats=False, out=None):
+    M, D = x.shape
+    if x.stride(1) != 1 or not x.is_cuda or x.dtype != torch.float32:
+        raise MMBError("layernorm_fwd: x must be a 2-D float32 HIP tensor with unit inner stride")
+    y = torch.empty(M, D, dtype=torch.float32, device=x.device) if out is None else out
+    stats = torch.empty(M, 2, dtype=torch.float32, device=x.device) if want_stats else None
+    call("mmb_layernorm_fwd", M, D, x.data_ptr(), x.stride(0), f32(gamma, "gamma"), f32(beta, "beta"), _fl(eps),
+         y.data_ptr(), y.stride(0), f32(stats), stream())
+    return (y, stats) if want_stats else y
+
+
+def layernorm_bwd(x, gamma, stats, dy, dx, accumulate, dgamma, dbeta):
+    """dx (M,D) overwritten or accumulated; dgamma/dbeta (D) accumulated with atomics (pre-zeroed)."""
+    M, D = x.shape
+    call("mmb_layernorm_bwd", M, D, x.data_ptr(), x.stride(0), f32(gamma, "gamma"), f32(stats), dy.data_ptr(),
+         dy.stride(0), dx.data_ptr(), dx.stride(0), int(bool(accumulate)), f32(dgamma), f32(dbeta), stream())
+
+
+def sum_replicas(src, dst, accumulate=False):
+    """src (R, n) replicas (row stride may exceed n) -> dst (n) contiguous."""
+    R, n = src.shape
+    call("mmb_sum_replicas", n, R, src.stride(0), src.data_ptr(), f32(dst.view(-1)), int(bool(accumulate)), stream())
+    return dst

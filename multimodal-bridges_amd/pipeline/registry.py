@@ -8,6 +8,7 @@ from model.bridges import UniformFlow, SchrodingerBridge, TelegraphBridge
 from model.thermostats import (ConstantThermostat, InverseThermostat, LinearThermostat, InverseSquareThermostat,
                                SigmoidThermostat)
 from encoders.multimodal_epic import UniModalEPiC, MultiModalEPiC
+from encoders.particle_transformer import MultiModalParticleTransformer
 
 registered_datasets = {}          # AspenOpenJets HDF5 reader: outside the hot path
 
@@ -16,7 +17,8 @@ registered_distributions = {"SourceUniform": SourceUniform}
 registered_bridges = {"UniformFlow": UniformFlow, "SchrodingerBridge": SchrodingerBridge,
                       "TelegraphBridge": TelegraphBridge}
 
-registered_models = {"UniModalEPiC": UniModalEPiC, "MultiModalEPiC": MultiModalEPiC}
+registered_models = {"UniModalEPiC": UniModalEPiC, "MultiModalEPiC": MultiModalEPiC,
+                     "MultiModalParticleTransformer": MultiModalParticleTransformer}
 
 registered_thermostats = {"ConstantThermostat": ConstantThermostat, "LinearThermostat": LinearThermostat,
                           "InverseThermostat": InverseThermostat,

@@ -159,6 +159,8 @@ def test_training_step_gradients(golden, name):
             continue
         scale = float(gref.abs().max()) + 1e-12
         close(got, gref, rtol=2e-3, atol=2e-4 * scale + 1e-7)
+    if g.grad_summaries():          # paper-size fixtures: norm + probe projection of EVERY parameter's gradient
+        g.check_grad_summaries(lambda n: params[n].grad, rtol=2e-3, atol_scale=2e-4)
     # quirks: the truncated embedding (Q1) and the never-executed fused layer (K2) get no gradient
     assert params["embedder.discrete_embedding.weight_v"].grad is None
 

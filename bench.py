@@ -1,24 +1,33 @@
 #!/usr/bin/env python3
 """Headline benchmark: generated jets/s @128 particles, 100 solver steps (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S3|S2] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S3|S2|S5|S4] [--batch B]
 
 One "step" = one full pass of the generation hot path over one batch of synthetic
 AOJ-shaped clouds per rank: on-device SourceUniform draw (multiplicity masks from the AOJ
 pmf) followed by the 100-point Euler / tau-leap loop (2 encoder forwards + K-B + K-C per grid
-point for S3).  Everything is resident in HBM; outputs stay on the device.  Ranks shard the
-jets (weak scaling), no collective on the data path.  Rank 0 prints ONE JSON line.
+point for S3).  Everything is resident in HBM; outputs stay on the device (the reference's
+predict_step ends in .cpu(): 9 MB per 1024 jets, 0.15 ms over PCIe against ~70 ms of compute --
+not in the timed region, see DESIGN.md "Host-buffer note").  Ranks shard the jets (weak scaling), no
+collective on the data path.  Rank 0 prints ONE JSON line.
+
+`--gpus N` with N > 1 and no torchrun environment: this process starts N ranks itself (a fresh
+`python -m torch.distributed.run` child, BEFORE anything here touches the GPU) and relays their output;
+under torchrun (WORLD_SIZE set) it is one of the ranks and checks that WORLD_SIZE == --gpus.
 
 Extra objects on the line:
-  roofline     -- the dominant kernel (the fp32-MFMA per-particle linear layer), timed live with
-                  HIP events on the launch stream during one extra profiled pass
+  roofline     -- the dominant kernel (the single-launch fused generation kernel: fp32 products formed from
+                  six bf16 MFMA partial products), timed live with HIP events on the launch stream over extra
+                  profiled passes; peak = the guide's dense bf16 MFMA peak, frac = EXECUTED MFMA flops / peak
   cpu_baseline -- the CPU oracle (op-for-op eager PyTorch restatement of the reference) timed
                   on the host cores over a bounded sample of the same workload (rank 0, N=1)
-  training     -- training jets/s of the same model (fwd+bwd+AdamW), when available
+  training     -- training jets/s of the same model (fwd+bwd+all-reduce+clip+AdamW)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,12 +40,11 @@ import torch  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense (the unfused per-layer kernels)
 PEAK_BF16_MFMA_TFLOPS = 2516.8     # same guide: v_mfma_f32_32x32x16_bf16, dense (16 x the f32 rate; no sparsity)
 # The fused kernels compute every fp32 product as six bf16 x bf16 partial products of a three-plane exact operand
-# split (csrc/fused_common.h: mma_x), so an fp32 flop costs six bf16 flops: the peak they are priced against.
-PEAK_FP32_ON_BF16_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6
+# split (csrc/fused_common.h: mma_x): the roofline counts those executed bf16 flops against the bf16 peak.
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {"S3": "configs/S3_multimodal.yaml", "S2": "configs/S2_discrete.yaml",
-             "S5": "configs/S5_large_generation.yaml"}
+             "S5": "configs/S5_large_generation.yaml", "S4": "configs/S4_transformer.yaml"}
 
 
 def build_model(workload, steps_per_gen, device):
@@ -71,11 +79,12 @@ def one_generation(model, config, B, device):
     return paths
 
 
-def profile_dominant_kernel(model, config, B, device):
-    """One extra generation pass with every C-ABI call bracketed by HIP events."""
+def profile_dominant_kernel(model, config, B, device, passes=3):
+    """Extra generation passes with every C-ABI call bracketed by HIP events (recorded on the launch stream)."""
     import mmb_hip
     mmb_hip.PROFILE = []
-    one_generation(model, config, B, device)
+    for _ in range(passes):
+        one_generation(model, config, B, device)
     torch.cuda.synchronize()
     rec, mmb_hip.PROFILE = mmb_hip.PROFILE, None
     groups = {}
@@ -92,15 +101,22 @@ def profile_dominant_kernel(model, config, B, device):
     return groups
 
 
+TRAFFIC_FILES = ("profiles/r2/pmc_traffic.json", "profiles/r1/pmc_traffic.json")
+
+
 def measured_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r1/pmc_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes)."""
-    path = os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            return json.load(fh).get(workload)
-    except (OSError, ValueError):
-        return None
+    """(HBM bytes per launch of the dominant kernel, file) from the newest committed rocprofv3 PMC passes of this
+    build's kernels (separate --pmc runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes) -- counters cannot
+    be read from inside this process, so this is the profile of the same command, not of this very run."""
+    for rel in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, rel)) as fh:
+                v = json.load(fh).get(workload)
+            if v is not None:
+                return v, rel
+        except (OSError, ValueError):
+            continue
+    return None, None
 
 
 def cpu_baseline(model, config, workload, n_jets, n_steps):
@@ -124,14 +140,32 @@ def cpu_baseline(model, config, workload, n_jets, n_steps):
         OM.simulate_dynamics(p, flat, src, noise=None, max_steps=n_steps)
     dt = time.perf_counter() - t0
     full = dt / n_steps * m.num_timesteps
+    scaled = "" if n_steps >= m.num_timesteps else ", scaled to the full grid"
     return {"value": n_jets / full, "unit": "jets/s", "cores": threads, "kind": "port",
-            "sample": f"{n_jets} jets x first {n_steps} of {m.num_timesteps} grid points of {workload} "
-                      f"(source sampling included), {dt:.1f} s measured, scaled to the full grid"}
+            "sample": f"{n_jets} jets x first {min(n_steps, m.num_timesteps)} of {m.num_timesteps} grid points of "
+                      f"{workload} (source sampling included), {dt:.1f} s measured{scaled}"}
 
 
 def trace(msg):
     if os.environ.get("MMB_BENCH_TRACE"):
         print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
+def launch_ranks(n):
+    """Start n ranks of this script under torch.distributed.run as a CHILD process and relay its exit code.  Called
+    before this process has made any GPU call (importing torch and counting devices do not initialise HIP), so no
+    GPU-initialised process is ever replaced or forked."""
+    ndev = torch.cuda.device_count()
+    if ndev < n and not os.environ.get("MMB_BENCH_REHEARSAL"):        # (rehearsal: CPU test of the launcher, gloo)
+        raise SystemExit(f"bench.py --gpus {n}: only {ndev} GPU(s) visible; refusing to report an n_gpus it did not use")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -146,14 +180,32 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="jets per rank per step")
     ap.add_argument("--solver-steps", type=int, default=0, help="grid points (0: the workload's own: 100, S5: 200)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-jets", type=int, default=128)
-    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-jets", type=int, default=256)
+    ap.add_argument("--cpu-steps", type=int, default=100)
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--train-only", action="store_true", help="time only the training step (S4 has no fused generation)")
+    ap.add_argument("--rendezvous-check", action="store_true",
+                    help="form the process group, all-reduce one number, print the world size and exit (launcher test)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher formed WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rendezvous_check:
+        import torch.distributed as dist
+        dist.init_process_group(os.environ.get("MMB_DIST_BACKEND", "nccl"))
+        one = torch.ones(1)
+        dist.all_reduce(one)
+        if dist.get_world_size() != args.gpus or int(one.item()) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+        if rank == 0:
+            print(json.dumps({"n_gpus": dist.get_world_size(), "rendezvous": "ok"}), flush=True)
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -169,6 +221,10 @@ def main():
         else:
             dist.init_process_group(backend)
 
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+        world = dist.get_world_size()
+
     trace("process group up")
     model, config = build_model(args.workload, args.solver_steps, device)
     trace("model built")
@@ -181,6 +237,34 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.train_only:
+        # S4 (BASELINE configs[3]) is a TRAINING config: data-parallel step of the transformer set encoder
+        from pipeline.experiment import bench_training
+        try:
+            tr = bench_training(model, config, B, device, dist, steps=args.steps, warmup=args.warmup)
+        except Exception:
+            if dist is None:
+                raise
+            import traceback
+            traceback.print_exc()
+            sys.stderr.flush()
+            os._exit(13)
+        if rank == 0:
+            print(json.dumps({
+                "metric": f"training jets/sec @{config.data.max_num_particles} particles", "value": tr["value"],
+                "unit": "jets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": tr["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]} -- {config.encoder.name}, "
+                                       f"N={config.data.max_num_particles}, training step",
+                           "jets_per_rank_per_step": B,
+                           "parallelism": f"data-parallel over {world} rank(s), one flat fp32 gradient all-reduce per step"},
+                "training": tr}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     for _ in range(args.warmup):
         one_generation(model, config, B, device)
@@ -206,6 +290,13 @@ def main():
             from pipeline.experiment import bench_training
             training = bench_training(model, config, B, device, dist, steps=max(args.steps * 5, 10), warmup=3)
         except Exception as exc:                                   # reported, never hidden
+            if dist is not None:
+                # the other ranks are (or will be) inside a collective this rank never joins: leave at once with a
+                # failure code so that the launcher takes every rank down instead of letting them hang
+                import traceback
+                traceback.print_exc()
+                sys.stderr.flush()
+                os._exit(13)
             training = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
@@ -221,25 +312,24 @@ def main():
             n_fwd = (2 if hybrid else 1) * args.solver_steps     # hybrid: one encoder forward per solver per grid point
             alg = float(fpp) * config.data.max_num_particles * B * n_fwd * fz["n"]
             achieved = alg / (fz["ms"] * 1e-3) / 1e12
-            tr = measured_traffic(args.workload)
+            tr, tr_file = measured_traffic(args.workload)
             # what the kernel's MFMAs really execute: the time/global-vector columns of every layer are hoisted
-            # into per-jet matvecs, so this is below the reference's algorithmic count (frac may exceed
-            # executed_frac, and 1.0, for that reason)
+            # into per-jet matvecs, so this is below the reference's algorithmic count; every fp32 product is six
+            # bf16 MFMA products, all of which count against the guide's dense bf16 peak
             ex_fpp = model._fused_pack()["mfma_flops_per_forward"]
             executed = float(ex_fpp) * config.data.max_num_particles * B * n_fwd * fz["n"] / (fz["ms"] * 1e-3) / 1e12
             kname = "fused_generate_kernel" if hybrid else "fused_uni_generate_kernel"
             roof = {"kernel": kname + " (whole generation loop; fp32 products as 6 x v_mfma_f32_32x32x16_bf16 over "
                                       "a 3-plane exact operand split)", "bound": "mfma",
-                    "achieved": achieved, "peak": PEAK_FP32_ON_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_FP32_ON_BF16_TFLOPS, "traffic": tr,
-                    "peak_basis": "bf16 dense MFMA peak 2516.8 TFLOP/s / 6 partial products per fp32 product; "
-                                  "achieved counts fp32 flops of the reference's layers",
-                    "frac_of_native_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+                    "achieved": 6 * executed, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": 6 * executed / PEAK_BF16_MFMA_TFLOPS, "traffic": tr, "traffic_source": tr_file,
+                    "peak_basis": "MI355X_MICROARCH.md dense bf16 MFMA peak; achieved = bf16 MFMA flops the kernel "
+                                  "executes (6 per fp32 multiply-add pair of the hoisted per-particle GEMMs)",
                     "executed_mfma_flops_per_particle_per_forward": ex_fpp,
-                    "executed_bf16_tflops": 6 * executed,
-                    "executed_frac": 6 * executed / PEAK_BF16_MFMA_TFLOPS,
-                    "launches": fz["n"], "avg_launch_us": fz["ms"] * 1e3 / fz["n"],
+                    "algorithmic_fp32_tflops": achieved,
+                    "algorithmic_frac_of_native_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
                     "algorithmic_flops_per_particle_per_forward": fpp, "forwards_per_launch": n_fwd,
+                    "launches": fz["n"], "avg_launch_us": fz["ms"] * 1e3 / fz["n"],
                     "share_of_gpu_time": fz["ms"] / total_ms}
         elif dom:
             achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
@@ -261,7 +351,7 @@ def main():
             "kernel_time_ms": {k: round(v["ms"], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])},
         }
         if training is not None:
-            tr_step = (measured_traffic("training_step") or {}).get(args.workload)
+            tr_step = (measured_traffic("training_step")[0] or {}).get(args.workload)
             if tr_step and B == 1024:                       # PMC passes were taken at 1024 jets per rank and step
                 per_rank = tr_step["bytes_per_step"]
                 training["hbm_traffic_bytes_per_rank_step"] = per_rank

@@ -394,8 +394,8 @@ struct WnBwdRow {
   const float* inv;       // its 1/||v||
   const float* dW;        // gradient of the effective row, replica 0
   const float* db_rep;    // bias-gradient element of this row, replica 0 (or NULL)
-  float* dv;              // outputs (overwritten)
-  float* dg;
+  float* dv;              // outputs: ACCUMULATED (+=) like every other gradient of the step, so that a second
+  float* dg;              // backward() without zeroing sums, as torch.autograd does
   float* db_out;          // (or NULL)
   int64_t len, reps, rep_stride, db_stride;
 };
@@ -416,13 +416,13 @@ weight_norm_bwd_multi_kernel(int n_rows, const WnBwdRow* __restrict__ rows) {
   const float gg = r.g[0];
   const float c1 = gg * inv;
   const float c2 = gg * dot * inv * inv * inv;
-  for (int k = threadIdx.x; k < len; k += 64) r.dv[k] = c1 * dw_at(k) - c2 * r.v[k];
+  for (int k = threadIdx.x; k < len; k += 64) r.dv[k] += c1 * dw_at(k) - c2 * r.v[k];
   if (threadIdx.x == 0) {
-    r.dg[0] = dot * inv;
+    r.dg[0] += dot * inv;
     if (r.db_out != nullptr) {
       float s = 0.0f;
       for (int q = 0; q < reps; ++q) s += r.db_rep[q * r.db_stride];
-      r.db_out[0] = s;
+      r.db_out[0] += s;
     }
   }
 }

@@ -125,12 +125,10 @@ def _produced(tape):
 
 
 def _direct(p, touched):
-    """The parameter's existing .grad buffer when this backward may OVERWRITE it: first contribution of
-    this pass and a contiguous pre-zeroed buffer (the flat all-reduce bucket) -- saves an add per parameter."""
-    if p.grad is None or id(p) in touched or not p.grad.is_contiguous():
-        return None
-    touched.add(id(p))
-    return p.grad.view(-1)
+    """Always None: gradients ACCUMULATE into an existing .grad (torch.autograd semantics -- a second backward()
+    without zeroing, or micro-batch accumulation, must sum).  An earlier version overwrote a pre-zeroed bucket here
+    to save one add per parameter."""
+    return None
 
 
 def param_grads(layer, segs, dZ, S, Sm, arena, touched):

@@ -386,9 +386,16 @@ class Workspace:
 
     def _wn_table(self, model):
         own = self.own_views
-        for p in self._params():                           # zero_grad(set_to_none=True) loops: hand the buffers back
-            if p.grad is None and id(p) in own:
+        back = [p for p in self._params() if p.grad is None and id(p) in own]
+        if back:                                           # zero_grad(set_to_none=True) loops: hand the buffers back,
+            whole = (len(back) == len(own) and self.own_grads is not None       # zeroed: the kernel ACCUMULATES
+                     and self.own_grads.numel() == sum(v.numel() for v in own.values()))   # into them (None == 0)
+            if whole:
+                self.own_grads.zero_()
+            for p in back:
                 p.grad = own[id(p)]
+                if not whole:
+                    p.grad.zero_()
         ptrs = tuple((p.data_ptr(), -1 if p.grad is None else p.grad.data_ptr()) for p in self._params())
         if ptrs == self.grad_ptrs:
             return

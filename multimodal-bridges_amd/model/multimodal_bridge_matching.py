@@ -349,8 +349,8 @@ class MultiModalBridgeMatching(nn.Module):
         solver_c = ContinuousSolver(self.config, model=self)
         solver_d = DiscreteSolver(self.config, model=self)
         call_id = self._next_offset() >> 8
-        for s in (solver_c, solver_d):
-            s.noise, s.seed, s.stream_id = noise, self.seed, call_id & 0xFFFFF
+        for s in (solver_c, solver_d):              # (call_id carries the rank above bit 40: keep both fields)
+            s.noise, s.seed, s.stream_id, s.rank = noise, self.seed, call_id & 0xFFFFF, self.rank
         first = state.clone()
         if state.has_discrete:
             state.discrete = state.discrete.clone()                   # the source tokens stay intact

@@ -30,6 +30,13 @@ def _time_args(state):
     return t.reshape(B, -1)[:, 0].contiguous().float(), 0.0
 
 
+def philox_offset(rank, tag, stream_id, step):
+    """64-bit Philox offset of one per-step kernel of the layered generation loop: rank (16 bits) | tag (4: which
+    draw) | generation call (20) | grid point (24).  The rank keeps the shards of a multi-GPU generation on
+    different streams (the seed is the same on every rank)."""
+    return ((rank & 0xFFFF) << 48) + ((tag & 0xF) << 44) + ((stream_id & 0xFFFFF) << 24) + (step & 0xFFFFFF)
+
+
 class _SolverBase:
     def __init__(self, config, model):
         self.model = model
@@ -37,9 +44,10 @@ class _SolverBase:
         self.step = 0
         self.seed = int(getattr(config, "seed", 0xA0A0))
         self.stream_id = 0
+        self.rank = int(getattr(model, "rank", 0) or 0)
 
     def _offset(self, tag):
-        return (tag << 44) + (self.stream_id << 24) + self.step
+        return philox_offset(self.rank, tag, self.stream_id, self.step)
 
 
 class ContinuousSolver(_SolverBase):

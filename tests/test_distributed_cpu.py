@@ -71,3 +71,38 @@ def test_shard_range_covers_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_launcher_forms_the_ranks_it_reports():
+    """`bench.py --gpus 2` without a torchrun environment starts its own ranks (a child torch.distributed.run, before
+    any GPU call) and the printed n_gpus is the size of the process group that really formed (gloo here)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MMB_DIST_BACKEND="gloo", MMB_BENCH_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--rendezvous-check"], env=env, capture_output=True,
+                       text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line) == {"n_gpus": 2, "rendezvous": "ok"}
+    # a launcher that formed a different world than --gpus asks for must fail loudly
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--rendezvous-check"], env=env2, capture_output=True,
+                       text=True, timeout=240)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_layered_philox_offsets_differ_across_ranks():
+    """the layered generation loop's per-step draws must not repeat across ranks."""
+    from model.solvers import philox_offset
+    seen = set()
+    for rank in (0, 1, 7):
+        for tag in (1, 2, 3):
+            for stream in (1, 2, 0xFFFFF):
+                for step in (0, 1, 199):
+                    o = philox_offset(rank, tag, stream, step)
+                    assert 0 <= o < 2 ** 64 and o not in seen
+                    seen.add(o)

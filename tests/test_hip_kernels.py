@@ -63,8 +63,9 @@ def test_telegraph_bridge(ops):
 
 def test_rate_and_jump_solvers(ops):
     z = load_npz("solvers")
-    kinds = {"ConstantThermostat": 0, "InverseSquareThermostat": 3}
-    for kname, gamma in (("ConstantThermostat", 0.125), ("ConstantThermostat", 0.075), ("InverseSquareThermostat", 0.125)):
+    kinds = {"ConstantThermostat": 0, "InverseThermostat": 1, "InverseSquareThermostat": 3}
+    for kname, gamma in (("ConstantThermostat", 0.125), ("ConstantThermostat", 0.075), ("InverseSquareThermostat", 0.125),
+                         ("InverseThermostat", 0.125)):
         tag = f"{kname}_{gamma}"
         kind = kinds[kname]
         t, logits, k, dt = T(z[tag + "_t"]), T(z[tag + "_logits"]), T(z[tag + "_k"]), float(z[tag + "_dt"])

@@ -179,6 +179,22 @@ int mmb_loss_fwd_bwd(int B, int N, int Dc, int V,
                      const float* vocab_freq, const float* coef,
                      float* partials, float* losses, float* d_head_c, float* d_head_d, void* stream);
 
+/* mmb_loss_fwd_bwd for callers that CANNOT ALLOCATE (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  Same arguments minus the `partials` workspace: the
+ * per-block partial sums live in a file-scope `static __device__` array of the library (2*MMB_LOSS_MAX_BLOCKS floats
+ * = 16 KiB, held by every GPU the library runs on until the process ends), whose device address is resolved with
+ * hipGetSymbolAddress once per device on the first call made with that device current (make that first call outside
+ * a graph capture).  Calls no hipMalloc / hipFree / allocating routine.  Limit: B*N <= 2^31 - 1 particles (rejected
+ * with MMB_ERR_INVALID_ARG beyond; the grid is capped at MMB_LOSS_MAX_BLOCKS blocks, so the scratch never grows).
+ * All calls on one GPU share that GPU's array: two calls that OVERLAP on one GPU (different streams) race on it;
+ * calls on one stream are ordered and need no clearing (every launch overwrites the partials it reads). */
+int mmb_loss_fwd_bwd_noalloc(int B, int N, int Dc, int V,
+                             const float* head_c, const float* head_d,
+                             const float* t, const float* xt, const float* x0, const float* x1, int bridge_kind,
+                             const int64_t* k1, const float* maskf, const int32_t* total,
+                             const float* vocab_freq, const float* coef,
+                             float* losses, float* d_head_c, float* d_head_d, void* stream);
+
 /* MultiModeLoss (multimodal_bridge_matching.py:268-306): learnable (s != NULL):
  * loss = sum_i 0.5*exp(-s_i)*L_i + 0.5*s_i ; fixed: sum_i w_i*L_i.
  * coef_out (2) = dLoss/dL_i ; d_s (2) | NULL = dLoss/ds_i. */
@@ -300,7 +316,8 @@ int mmb_grad_weight_smallk(int M, const float* X, int64_t x_ld, int K, const flo
  * mmb_weight_norm_multi: one record per row {v row, g element | NULL = plain copy, destination row, 1/||v||
  *   destination | NULL, length} -- torch.nn.utils.weight_norm as used in epic.py:4,67,132-141,180-183, embedder.py:61.
  * mmb_weight_norm_bwd_multi: one record per row {v, g, inv, dW row (replica 0), db element (replica 0) | NULL,
- *   dv out, dg out, db out | NULL, length, replicas, replica stride of dW, of db}; outputs are overwritten.
+ *   dv out, dg out, db out | NULL, length, replicas, replica stride of dW, of db}; outputs are ACCUMULATED (+=), like
+ *   autograd accumulates into .grad: zero them before the first backward of a step.
  * mmb_grad_weight_rows_multi: records {X, dZ, dW, db | NULL, x_ld, dz_ld, dw_ld, rep_stride, db_stride, M, K, Nout,
  *   rows per block, replicas, blocks along rows, blocks along K windows, first block id, end block id}, all of tile
  *   class (OTb, KTb) = mmb_hip.ops.gw_class(K, Nout); semantics per record as mmb_grad_weight_rows (fast path only:

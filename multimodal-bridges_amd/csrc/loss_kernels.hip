@@ -1,6 +1,13 @@
 // K-F: masked MSE + masked cross-entropy, forward and head gradients in one pass; mask
 // canonicalisation; MultiModeLoss.  Reference: model/multimodal_bridge_matching.py:165-192,268-306.
 #include "common.h"
+#include <mutex>
+
+// Scratch of mmb_loss_fwd_bwd_noalloc: the per-block partial sums (2 floats per block, at most
+// MMB_LOSS_MAX_BLOCKS blocks = 16 KiB) that mmb_loss_fwd_bwd takes as its caller-provided `partials` workspace.
+// Every GPU the library runs on holds its own copy of this array for the life of the process.  In host code the
+// NAME below is only a stand-in for the symbol: kernels get the per-device address from hipGetSymbolAddress.
+static __device__ __align__(256) float scratch[2 * MMB_LOSS_MAX_BLOCKS];
 
 namespace mmb {
 
@@ -179,7 +186,8 @@ extern "C" int mmb_loss_fwd_bwd(int B, int N, int Dc, int V, const float* head_c
                                 const float* vocab_freq, const float* coef, float* partials, float* losses,
                                 float* d_head_c, float* d_head_d, void* stream) {
   MMB_REQUIRE(B > 0 && N > 0, "mmb_loss_fwd_bwd: empty shape");
-  MMB_REQUIRE((int64_t)B * N < (1ll << 31), "mmb_loss_fwd_bwd: B*N too large");
+  MMB_REQUIRE((int64_t)B * N < (1ll << 31), "mmb_loss_fwd_bwd: B*N = %lld particles is beyond the maximum of 2^31 - 1",
+              (long long)B * N);
   MMB_REQUIRE(head_c || head_d, "mmb_loss_fwd_bwd: no head given");
   MMB_REQUIRE(maskf && total && partials && losses, "mmb_loss_fwd_bwd: NULL argument");
   if (head_c) MMB_REQUIRE(t && xt && x0 && x1 && Dc > 0, "mmb_loss_fwd_bwd: continuous head needs t,xt,x0,x1");
@@ -200,6 +208,54 @@ extern "C" int mmb_loss_fwd_bwd(int B, int N, int Dc, int V, const float* head_c
   if (rc) return rc;
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), grid, partials, total, losses);
   return check_launch("mmb_loss_fwd_bwd(finalize)");
+}
+
+// ---- the entry point that allocates nothing (no counterpart in the reference) ----------------------------------
+namespace {
+constexpr int kMaxDevices = 64;
+float* g_scratch_ptr[kMaxDevices];          // per device: each GPU holds its own copy of `scratch` at its own address
+std::mutex g_scratch_mutex;
+
+// device address of `scratch` on the CURRENT device, resolved once per device (no allocation: the array is part
+// of the code object)
+int scratch_on_current_device(float** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    mmb::set_error("mmb_loss_fwd_bwd_noalloc: hipGetDevice failed or device %d outside [0,%d): %s", dev, kMaxDevices,
+                   hipGetErrorString(e));
+    return MMB_ERR_LAUNCH;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[dev] == nullptr) {
+    float* p = nullptr;
+    e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr) {
+      mmb::set_error("mmb_loss_fwd_bwd_noalloc: hipGetSymbolAddress(scratch) failed on device %d: %s", dev,
+                     hipGetErrorString(e));
+      return MMB_ERR_LAUNCH;
+    }
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return MMB_OK;
+}
+}  // namespace
+
+extern "C" int mmb_loss_fwd_bwd_noalloc(int B, int N, int Dc, int V, const float* head_c, const float* head_d,
+                                        const float* t, const float* xt, const float* x0, const float* x1,
+                                        int bridge_kind, const int64_t* k1, const float* maskf, const int32_t* total,
+                                        const float* vocab_freq, const float* coef, float* losses, float* d_head_c,
+                                        float* d_head_d, void* stream) {
+  MMB_REQUIRE(B > 0 && N > 0, "mmb_loss_fwd_bwd_noalloc: empty shape");
+  MMB_REQUIRE((int64_t)B * N < (1ll << 31),
+              "mmb_loss_fwd_bwd_noalloc: B*N = %lld particles is beyond the maximum of 2^31 - 1", (long long)B * N);
+  float* ptr = nullptr;
+  if (int rc = scratch_on_current_device(&ptr)) return rc;
+  // every block overwrites its own partial pair and the finalize kernel reads exactly the pairs of this launch's
+  // grid: nothing in the scratch has to start at zero, a previous (larger) call's leftovers are never read
+  return mmb_loss_fwd_bwd(B, N, Dc, V, head_c, head_d, t, xt, x0, x1, bridge_kind, k1, maskf, total, vocab_freq, coef,
+                          ptr, losses, d_head_c, d_head_d, stream);
 }
 
 extern "C" int mmb_multimode_coef(const float* s, const float* fixed_w_host2, float* coef_out, void* stream) {

@@ -40,6 +40,8 @@ SIGNATURES = {
                             C.c_float, c_f32p, C.c_uint64, C.c_uint64, C.c_int, c_f32p, c_stream],
     "mmb_loss_fwd_bwd": [C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                          C.c_int, c_i64p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
+    "mmb_loss_fwd_bwd_noalloc": [C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                 C.c_int, c_i64p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
     "mmb_multimode_coef": [c_f32p, C.POINTER(C.c_float), c_f32p, c_stream],
     "mmb_multimode_loss": [c_f32p, c_f32p, C.POINTER(C.c_float), c_f32p, c_f32p, c_stream],
     "mmb_weight_norm": [C.c_int, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],

@@ -334,6 +334,20 @@ int mmb_pack_params(const float* flat, const int64_t* gather, const int64_t* gat
                     const int64_t* gather_x, int64_t n_x, float* dst, void* stream);
 int mmb_grad_weight_rows_multi(int OTb, int KTb, const void* probs, int n_probs, int total_blocks, void* stream);
 
+/* ---------------------------------------------------------------- optimizer step ----- */
+#define MMB_ADAMW_MAX_PARTIALS 1024
+/* The optimizer step of the training loop on flat buffers: Lightning's gradient_clip_val (global L2 norm,
+ * pipeline/experiment.py:217: g *= min(1, max_norm/(||g|| + 1e-6)) over all n gradients) followed by
+ * torch.optim.AdamW (multimodal_bridge_matching.py:151-154; decoupled weight decay, bias-corrected moments, no
+ * amsgrad) on the first n_active elements -- parameters that never receive a gradient upstream (grad None there:
+ * the truncated embedding Q1, the dead fused layer K2) are laid out behind n_active and left untouched, as
+ * torch skips them.  lr is this step's learning rate, step counts from 1.  max_norm <= 0 disables clipping.
+ * partials: workspace of MMB_ADAMW_MAX_PARTIALS floats (clipping only); norm_out (1) | NULL receives ||g||;
+ * write_clipped != 0 also stores the clipped gradients back (what clip_grad_norm_ leaves in .grad). */
+int mmb_adamw_clip_step(int64_t n, int64_t n_active, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                        float max_norm, float* partials, float* norm_out, int write_clipped, void* stream);
+
 /* ---------------------------------------------------------------- transformer set encoder */
 /* TransformerEncoderBlock (encoders/particle_transformer.py:8-50) = torch's nn.TransformerEncoderLayer (post-LN,
  * ReLU FFN, batch_first) over the particles of one jet.  The Linear layers (input/time projection, in_proj,

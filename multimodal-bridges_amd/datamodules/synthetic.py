@@ -20,7 +20,7 @@ def load_pmf(metadata_dir):
         return json.load(fh)["categorical_probs"]
 
 
-def synthetic_target(B, N, metadata_dir, seed=1234, Dc=3, V=8, modality="multi-modal", device="cpu",
+def synthetic_target(B, N=128, metadata_dir=None, seed=1234, Dc=3, V=8, modality="multi-modal", device="cpu",
                      masks="sampled") -> TensorMultiModal:
     g = torch.Generator().manual_seed(seed)
     if masks == "ones":
@@ -57,31 +57,57 @@ class SyntheticJetDataModule:
     def setup(self, stage=None, rank=0, world=1, device="cuda"):
         d = self.config.data
         n = int(d.num_jets or 1024)
-        full = synthetic_target(n, d.max_num_particles, d.target_path, seed=1234, Dc=max(d.dim_continuous, 1),
-                                V=d.vocab_size, modality=d.modality, device=device)
         ratios = d.split_ratios or [0.8, 0.2]
         n_train = int(ratios[0] * n)
+        self._args = dict(N=d.max_num_particles, metadata_dir=d.target_path, Dc=max(d.dim_continuous, 1), V=d.vocab_size,
+                          modality=d.modality, device=device)
+        self._rank, self._device = rank, device
+        nv = n - n_train
+        base, rem = divmod(nv, world)
+        self._n_test = base + (1 if rank < rem else 0)
+        if stage == "predict":
+            # generation only needs the SHAPE of the target batch (the masks come from the source sampler, K4): the
+            # rank's shard is drawn chunk by chunk in predict_dataloader, never as one 1M-jet host tensor
+            self._train = self._val = self._test = None
+            return
+        full = synthetic_target(n, seed=1234, **self._args)
         base, rem = divmod(n_train, world)
         lo = rank * base + min(rank, rem)
         hi = lo + base + (1 if rank < rem else 0)
         self._train = full[lo:hi]
-        nv = n - n_train
         base, rem = divmod(nv, world)
         lo = n_train + rank * base + min(rank, rem)
         hi = lo + base + (1 if rank < rem else 0)
         self._val = full[lo:hi]
         self._test = self._val
 
-    def _batches(self, data):
+    def _batches(self, data, perm=None):
         bs = int(self.config.data.batch_size)
+        out = []
         for i in range(0, len(data), bs):
-            yield DataCoupling(TensorMultiModal(), data[i:i + bs], None)
+            part = data[i:i + bs] if perm is None else data[perm[i:i + bs]]
+            out.append(DataCoupling(TensorMultiModal(), part, None))
+        return out
 
-    def train_dataloader(self):
-        return self._batches(self._train)
+    def train_dataloader(self, epoch=None):
+        """A list of batches; reshuffled per epoch with a seeded device permutation (shuffle=True upstream,
+        jetmodule.py:102)."""
+        perm = None
+        if epoch is not None:
+            g = torch.Generator(device="cpu").manual_seed(0x5EED + 7919 * int(epoch) + self._rank)
+            perm = torch.randperm(len(self._train), generator=g).to(self._train.mask.device)
+        return self._batches(self._train, perm)
 
     def val_dataloader(self):
         return self._batches(self._val)
 
     def predict_dataloader(self):
-        return self._batches(self._test)
+        """This rank's shard of the test jets in chunks of batch_size (S5: 125 000 jets per rank in chunks of 8192)."""
+        if self._test is not None:
+            yield from self._batches(self._test)
+            return
+        bs = int(self.config.data.batch_size)
+        for i, lo in enumerate(range(0, self._n_test, bs)):
+            nb = min(bs, self._n_test - lo)
+            yield DataCoupling(TensorMultiModal(), synthetic_target(nb, seed=99991 * (self._rank + 1) + i, **self._args),
+                               None)

@@ -102,6 +102,8 @@ SIGNATURES = {
     "mmb_layernorm_bwd": [C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64,
                           C.c_int, c_f32p, c_f32p, c_stream],
     "mmb_sum_replicas": [C.c_int64, C.c_int, C.c_int64, c_f32p, c_f32p, C.c_int, c_stream],
+    "mmb_adamw_clip_step": [C.c_int64, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_float, C.c_float,
+                            C.c_float, C.c_float, C.c_int64, C.c_float, c_f32p, c_f32p, C.c_int, c_stream],
     "mmb_grad_weight": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
                         C.POINTER(C.c_int), c_f32p, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p, c_stream],
 }

@@ -568,3 +568,16 @@ def sum_replicas(src, dst, accumulate=False):
     R, n = src.shape
     call("mmb_sum_replicas", n, R, src.stride(0), src.data_ptr(), f32(dst.view(-1)), int(bool(accumulate)), stream())
     return dst
+
+
+# ------------------------------------------------------------------------ optimizer step
+ADAMW_WS = 1024
+
+
+def adamw_clip_step_(params, grads, exp_avg, exp_avg_sq, n_active, lr, betas, eps, weight_decay, step, max_norm,
+                     partials, norm_out=None, write_clipped=False):
+    """Global-norm clip + AdamW on flat fp32 buffers, in place, two launches, no host sync."""
+    call("mmb_adamw_clip_step", params.numel(), int(n_active), f32(params, "params"), f32(grads, "grads"),
+         f32(exp_avg, "exp_avg"), f32(exp_avg_sq, "exp_avg_sq"), _fl(lr), _fl(betas[0]), _fl(betas[1]), _fl(eps),
+         _fl(weight_decay), int(step), _fl(max_norm or 0.0), f32(partials, "partials"), f32(norm_out, "norm_out"),
+         int(bool(write_clipped)), stream())

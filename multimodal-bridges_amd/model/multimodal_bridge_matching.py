@@ -135,6 +135,13 @@ class MultiModalBridgeMatching(nn.Module):
         ver = fused_epic.params_version(self)
         if self._fused_cache is None:
             self._fused_cache = (ver, fused_epic.pack_model(self))
+            if self._fused_cache[1] is None and not getattr(self, "_warned_layered", False):
+                self._warned_layered = True                     # tell the user ONCE that they are off the fast path
+                e = self.config.encoder
+                print(f"[mmb] {e.name} with dim_hidden_local={e.dim_hidden_local}, dim_hidden_glob={e.dim_hidden_glob}, "
+                      f"dim_emb_time={e.dim_emb_time} is not one of the compiled fused variants "
+                      f"(mmb_hip/fused.py: VARIANTS / UNI_VARIANTS; V = 8, Dc = 3, N <= 128): running the layered "
+                      f"HIP path, several times slower in generation and training", flush=True)
         elif self._fused_cache[0] != ver:
             old = self._fused_cache[1]
             if old is not None and "gather" in old and old["packed"].device == self.device:

@@ -65,6 +65,68 @@ class FlatGrads:
         return norm
 
 
+def make_optimizer(model, config):
+    """-> (optimizer, scheduler | None, flat): FlatAdamW (clip + AdamW in two launches on flat buffers, its own
+    gradient bucket) when the config asks for AdamW, else the registry's torch optimizer + a FlatGrads bucket."""
+    from pipeline.registry import registered_optimizers, registered_schedulers
+    tr = config.trainer
+    params = dict(tr.optimizer_params or {})
+    if tr.optimizer_name == "AdamW" and not params.get("amsgrad"):
+        from pipeline.optim import FlatAdamW, unused_parameter_names
+        params.pop("amsgrad", None)
+        opt = FlatAdamW(model.named_parameters(), unused=unused_parameter_names(model), **params)
+        flat = opt
+    else:
+        opt = registered_optimizers[tr.optimizer_name](model.parameters(), **params)
+        flat = FlatGrads(model.parameters())
+    sched = None
+    if tr.scheduler_name:
+        sched = registered_schedulers[tr.scheduler_name](opt, **(tr.scheduler_params or {}))
+    return opt, sched, flat
+
+
+def optimizer_step(opt, flat, max_norm):
+    if flat is opt:
+        opt.step(max_norm=max_norm)
+    else:
+        flat.clip_(max_norm)
+        opt.step()
+
+
+def gather_generated(gen, dist, rank, world):
+    """ONE tensor gather of the generated shards to rank 0 (the reference concatenates per-rank files,
+    callbacks_generator.py:53-70).  x (J,N,Dc) f32, k (J,N,1), mask (J,N,1) are packed into one (Jmax, N, Dc+2) f32
+    tensor per rank (tokens and masks are small integers: exact in f32); shards may differ by one jet, so they are
+    padded to the largest and cut back on rank 0.  Returns the concatenation on rank 0, None elsewhere."""
+    dev = gen.mask.device
+    J, N = gen.mask.shape[0], gen.mask.shape[1]
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    counts[rank] = J
+    dist.all_reduce(counts)
+    jmax = int(counts.max())
+    has_c, has_d = gen.has_continuous, gen.has_discrete
+    Dc = gen.continuous.shape[-1] if has_c else 0
+    width = Dc + (1 if has_d else 0) + 1
+    pack = torch.zeros(jmax, N, width, dtype=torch.float32, device=dev)
+    if has_c:
+        pack[:J, :, :Dc] = gen.continuous
+    if has_d:
+        pack[:J, :, Dc] = gen.discrete.squeeze(-1).float()
+    pack[:J, :, -1] = gen.mask.squeeze(-1).float()
+    host = dist.get_backend() == "gloo" and pack.is_cuda                     # rehearsal only
+    buf = pack.cpu() if host else pack
+    parts = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, parts, dst=0)
+    if rank != 0:
+        return None
+    outs = []
+    for r, part in enumerate(parts):
+        part = part[:int(counts[r])].to(dev)
+        outs.append(TensorMultiModal(None, part[..., :Dc].contiguous() if has_c else None,
+                                     part[..., Dc:Dc + 1].long() if has_d else None, part[..., -1:].long()))
+    return TensorMultiModal.cat(outs, dim=0)
+
+
 def shard_range(n_items, rank, world):
     """Contiguous shard [lo, hi) of rank; shards differ by at most one item."""
     base, rem = divmod(n_items, world)
@@ -109,10 +171,15 @@ class ExperimentPipeline:
             self.config = config if isinstance(config, ExperimentConfigs) else ExperimentConfigs(config)
             self.config.update(config_updates or {})
             self.experiment_path = self.config.path or self.config.checkpoints.dirpath
+            if self.experiment_path is None and self.rank == 0:
+                print("[ExperimentPipeline] checkpoints.dirpath is null: nothing will be saved (no checkpoints, no "
+                      "metrics.jsonl, no generated sample)", flush=True)
             self.model = MultiModalBridgeMatching(self.config)
             self._resume = None
         self.model.to(self.device)
         self.model.manual_seed(0xA0A0, self.rank)
+        if self._resume is not None and "philox_calls" in self._resume:
+            self.model._calls = int(self._resume["philox_calls"])          # resumed epochs draw NEW noise streams
         if self.dist is not None:                                  # identical initial weights on every rank
             for p in self.model.parameters():
                 self.dist.broadcast(p.data, src=0)
@@ -135,16 +202,29 @@ class ExperimentPipeline:
         torch.save({"state_dict": {k: v.cpu() for k, v in self.model.state_dict().items()},
                     "optimizer": optimizer.state_dict(),
                     "scheduler": scheduler.state_dict() if scheduler else None, "epoch": epoch,
+                    "philox_calls": int(self.model._calls),
                     "config": self.config.to_dict()}, os.path.join(d, f"{name}.ckpt"))
+
+    def _write_metadata(self):
+        """Target statistics next to the checkpoints (the reference's datamodule writes metadata.json into the
+        experiment directory; generate() reads it back to invert the data transform)."""
+        meta = getattr(self.datamodule, "metadata", None)
+        if meta and self.rank == 0 and self.experiment_path:
+            os.makedirs(self.experiment_path, exist_ok=True)
+            with open(os.path.join(self.experiment_path, "metadata.json"), "w") as fh:
+                json.dump(meta, fh)
+
+    def _min_over_ranks(self, n):
+        if self.dist is None:
+            return n
+        t = torch.tensor([n], dtype=torch.int64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return int(t.item())
 
     def train(self):
         cfg = self.config
         model = self.model.train()
-        opt = model.configure_optimizers()
-        sched = None
-        if isinstance(opt, tuple) or isinstance(opt, list):
-            opt, sched = opt[0][0], opt[1][0]
-        flat = FlatGrads(model.parameters())
+        opt, sched, flat = make_optimizer(model, cfg)
         start = 0
         if self._resume is not None:
             opt.load_state_dict(self._resume["optimizer"])
@@ -152,18 +232,27 @@ class ExperimentPipeline:
                 sched.load_state_dict(self._resume["scheduler"])
             start = int(self._resume["epoch"]) + 1
         self.datamodule.setup("fit", rank=self.rank, world=self.world, device=self.device)
+        self._write_metadata()
         best = float("inf")
         for epoch in range(start, cfg.trainer.max_epochs):
             model.train()
             acc = torch.zeros(3, device=self.device)
             n = 0
-            for batch in self.datamodule.train_dataloader():
+            try:
+                loader = self.datamodule.train_dataloader(epoch=epoch)      # reshuffled every epoch (shuffle=True upstream)
+            except TypeError:
+                loader = self.datamodule.train_dataloader()
+            batches = list(loader) if not hasattr(loader, "__len__") else loader
+            # every step ends in a collective: all ranks must run the SAME number of steps (shards differ by a jet)
+            n_steps = self._min_over_ranks(len(batches))
+            for batch in batches:
+                if n >= n_steps:
+                    break
                 flat.zero()
                 out = model.training_step(batch, n)
                 out["loss"].backward()
                 flat.all_reduce_mean(self.dist, self.world)
-                flat.clip_(cfg.trainer.gradient_clip_val)
-                opt.step()
+                optimizer_step(opt, flat, cfg.trainer.gradient_clip_val)
                 acc += torch.stack([out["loss"].detach(), out["train_loss_continuous"], out["train_loss_discrete"]])
                 n += 1
             if sched is not None:
@@ -194,6 +283,14 @@ class ExperimentPipeline:
         the device (pipeline/postprocess.py; reference GeneratorCallback._postprocess); rank 0 receives the
         concatenation."""
         model = self.model.eval()
+        transform = getattr(self.config.data, "transform", None)
+        metadata = None
+        if postprocess and transform is not None:            # fail BEFORE generating, not after
+            if not self.experiment_path:
+                raise RuntimeError("generate(): data.transform is set but there is no experiment_path to read the "
+                                   "target statistics (metadata.json) from; set checkpoints.dirpath")
+            with open(os.path.join(self.experiment_path, "metadata.json")) as fh:
+                metadata = json.load(fh)
         self.datamodule.setup("predict", rank=self.rank, world=self.world, device=self.device)
         outs = []
         for i, batch in enumerate(self.datamodule.predict_dataloader()):
@@ -202,17 +299,9 @@ class ExperimentPipeline:
         gen = TensorMultiModal.cat(outs, dim=0)
         if postprocess:
             from pipeline.postprocess import postprocess as _post
-            transform = getattr(self.config.data, "transform", None)
-            metadata = None
-            if transform is not None:                     # statistics written next to the checkpoints at training time
-                import json
-                with open(os.path.join(self.experiment_path, "metadata.json")) as fh:
-                    metadata = json.load(fh)
             gen = _post(gen, transform, metadata, getattr(self.config.data, "discrete_features", "tokens"))
         if gather and self.dist is not None:
-            parts = [None] * self.world
-            self.dist.all_gather_object(parts, gen.cpu())
-            gen = TensorMultiModal.cat(parts, dim=0) if self.rank == 0 else None
+            gen = gather_generated(gen, self.dist, self.rank, self.world)
         if self.rank == 0 and gen is not None and self.experiment_path:
             os.makedirs(self.experiment_path, exist_ok=True)
             gen.cpu().save_to(os.path.join(self.experiment_path, "generated_sample.h5"))
@@ -229,8 +318,7 @@ def bench_training(model, config, B, device, dist, steps=10, warmup=3):
     tgt = synthetic_target(B, config.data.max_num_particles, config.data.target_path, seed=1234 + rank,
                            Dc=max(config.data.dim_continuous, 1), V=config.data.vocab_size,
                            modality=config.data.modality, device=device)
-    opt = torch.optim.AdamW(model.parameters(), **{k: v for k, v in config.trainer.optimizer_params.items()})
-    flat = FlatGrads(model.parameters())
+    opt, _, flat = make_optimizer(model, config)
 
     def step(i):
         flat.zero()
@@ -238,8 +326,7 @@ def bench_training(model, config, B, device, dist, steps=10, warmup=3):
         out = model.training_step(batch, i)
         out["loss"].backward()
         flat.all_reduce_mean(dist, world)
-        flat.clip_(config.trainer.gradient_clip_val)
-        opt.step()
+        optimizer_step(opt, flat, config.trainer.gradient_clip_val)
         return out["loss"]
 
     for i in range(warmup):
@@ -263,4 +350,5 @@ def bench_training(model, config, B, device, dist, steps=10, warmup=3):
         p.grad = None
     return {"value": B * world * steps / dt, "unit": "jets/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "global_batch": B * world, "dropout": config.encoder.dropout, "final_loss": float(loss.detach()),
+            "optimizer": type(opt).__name__,
             "includes": "bridge sampling, fwd, loss, bwd, grad all-reduce, clip, AdamW"}

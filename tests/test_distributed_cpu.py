@@ -41,7 +41,28 @@ def _worker(rank, world, port, q):
     norm = flat.clip_(1.0)
     ok_clip = abs(float(torch.linalg.vector_norm(flat.flat)) - min(1.0, float(norm))) < 1e-4
     lo, hi = shard_range(1001, rank, world)
-    q.put((rank, ok_mean, ok_frozen, ok_clip, lo, hi))
+    # the single tensor gather of generate(): shards that differ by one jet, rank 0 gets the concatenation in rank order
+    from pipeline.experiment import gather_generated
+    from tensorclass import TensorMultiModal
+    J = 3 + rank
+    g = torch.Generator().manual_seed(rank)
+    gen = TensorMultiModal(None, torch.randn(J, 5, 3, generator=g), torch.randint(0, 8, (J, 5, 1), generator=g),
+                           torch.randint(0, 2, (J, 5, 1), generator=g))
+    got = gather_generated(gen, dist, rank, world)
+    ok_gather = True
+    if rank == 0:
+        want_parts = []
+        for r in range(world):
+            gr = torch.Generator().manual_seed(r)
+            want_parts.append((torch.randn(3 + r, 5, 3, generator=gr), torch.randint(0, 8, (3 + r, 5, 1), generator=gr),
+                               torch.randint(0, 2, (3 + r, 5, 1), generator=gr)))
+        ok_gather = (torch.equal(got.continuous, torch.cat([w[0] for w in want_parts]))
+                     and torch.equal(got.discrete, torch.cat([w[1] for w in want_parts]))
+                     and torch.equal(got.mask, torch.cat([w[2] for w in want_parts]))
+                     and got.discrete.dtype == torch.int64 and got.mask.dtype == torch.int64)
+    else:
+        ok_gather = got is None
+    q.put((rank, ok_mean, ok_frozen, ok_clip and ok_gather, lo, hi))
     dist.barrier()
     dist.destroy_process_group()
 

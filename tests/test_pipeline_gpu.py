@@ -56,3 +56,57 @@ def test_evaluate_report_on_device():
     assert all(v >= 0.0 for v in rep.values()) and rep["pt"] > 0.0
     same = wasserstein_report(a, a, features=["pt", "numParticles"])
     assert same == {"pt": 0.0, "numParticles": 0.0}
+
+
+@pytest.mark.parametrize("name", ["mm_mid", "uni_mid"])
+def test_flat_adamw_matches_torch_adamw_with_clipping(golden, name):
+    """FlatAdamW (mmb_adamw_clip_step: clip + AdamW in two launches on flat buffers) against
+    torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW over several steps with a changing learning rate; the
+    parameters whose gradient is None upstream (Q1 embedding, K2 dead layer) must not move -- torch skips them."""
+    from pipeline.configs import ExperimentConfigs
+    from model.multimodal_bridge_matching import MultiModalBridgeMatching
+    from pipeline.optim import FlatAdamW, unused_parameter_names
+    g = golden(name)
+    cfg = copy.deepcopy(g.cfg)
+    cfg["data"]["target_path"] = GOLDEN
+    a = MultiModalBridgeMatching(ExperimentConfigs(copy.deepcopy(cfg)))
+    a.load_state_dict(g.params)
+    b = MultiModalBridgeMatching(ExperimentConfigs(copy.deepcopy(cfg)))
+    b.load_state_dict(g.params)
+    a, b = a.cuda(), b.cuda()
+    unused = unused_parameter_names(a)
+    assert any(n.startswith("embedder.discrete_embedding") for n in unused)
+    if name == "mm_mid":
+        assert any("fused_encoder.epic_layers.2." in n for n in unused)
+    hp = dict(lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    fa = FlatAdamW(a.named_parameters(), unused=unused, **hp)
+    ta = torch.optim.AdamW([p for p in b.parameters() if p.requires_grad], **hp)
+    before = {n: p.detach().clone() for n, p in a.named_parameters()}
+    gen = torch.Generator().manual_seed(5)
+    for it in range(6):
+        lr = 3e-3 * (1.0 - 0.1 * it)
+        fa.param_groups[0]["lr"] = ta.param_groups[0]["lr"] = lr
+        fa.zero()
+        for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+            if not pa.requires_grad:
+                continue
+            if n in unused:
+                pb.grad = None                                 # as upstream: never touched by backward
+                continue
+            gr = (torch.randn(pa.shape, generator=gen) * (3.0 if it % 2 else 0.01)).cuda()     # clipped / not clipped
+            pa.grad.copy_(gr)
+            pb.grad = gr.clone()
+        norm = torch.nn.utils.clip_grad_norm_([p for p in b.parameters() if p.grad is not None], 1.0)
+        ta.step()
+        fa.step(max_norm=1.0)
+        torch.testing.assert_close(fa.last_norm[0].cpu(), norm.cpu(), rtol=1e-5, atol=1e-7)
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        torch.testing.assert_close(pa.detach().cpu(), pb.detach().cpu(), rtol=2e-5, atol=2e-7, msg=lambda m: f"{n}: {m}")
+        if n in unused:
+            assert torch.equal(pa.detach().cpu(), before[n].cpu())
+    # the weight caches see the raw-pointer update
+    assert all(p._version > 0 for p in a.parameters() if p.requires_grad)
+    sd = fa.state_dict()
+    fa2 = FlatAdamW(a.named_parameters(), unused=unused, **hp)
+    fa2.load_state_dict(sd)
+    assert fa2.t == 6 and torch.equal(fa2.exp_avg, fa.exp_avg)

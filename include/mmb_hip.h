@@ -49,6 +49,7 @@ extern "C" {
 #define MMB_ACT_GELU 1   /* exact erf form, nn.GELU() default  (epic.py:124) */
 #define MMB_ACT_LRELU 2  /* leaky_relu slope 0.01              (epic.py:172) */
 #define MMB_ACT_RELU 3   /* nn.TransformerEncoderLayer's FFN activation (particle_transformer.py:29-35) */
+#define MMB_ACT_SELU 4   /* torch.nn.SELU of the toy MLP (notebooks/data_toys.ipynb cell 3) */
 
 /* segment kinds of a concatenated linear input (mmb_linear_cat) */
 #define MMB_SEG_ROW 0       /* (M,K_s) one row per particle                              */
@@ -486,6 +487,21 @@ int mmb_fused_uni_generate(int variant, int B, int N, const float* packed, const
                            const float* ctab_steps, int n_ctab, float dt,
                            int thermo_kind, float gamma, const float* delta_n,
                            uint64_t seed, uint64_t offset, void* stream);
+
+/* ---------------------------------------------------------------- toy config (BASELINE configs[0]) */
+/* Input rows of the toy MLP: rows[p,:] = [t(jet of p), x[p,0:Dc], table[k[p],0:E]]  (P, 1+Dc+E) --
+ * MultiModalMLP.forward's torch.cat([time, continuous, embed(discrete)]) (notebooks/data_toys.ipynb cell 3).
+ * t: one value per jet (t_stride 1) or one scalar for all (t_stride 0); table (V,E) is nn.Embedding.weight. */
+int mmb_toy_rows(int64_t P, int N, int Dc, int E, int V, const float* t, int64_t t_stride, const float* x,
+                 const int64_t* k, const float* table, float* rows, void* stream);
+/* autograd of that nn.Embedding: d_table[k[p], e] += d_rows[p, col0+e]  (d_table accumulates). */
+int mmb_toy_embedding_bwd(int64_t P, int E, int V, const int64_t* k, const float* d_rows, int64_t ld, int col0,
+                          float* d_table, void* stream);
+/* Toy distributions on device (distributions/toys.py): kind 0 = NGaussians.__call__ (:15-43; point i in gaussian
+ * i % V, centres on the radius-5 circle, covariance sqrt(0.1) I), kind 1 = TwoMoons.__call__ (:49-55;
+ * generate_moons(n, noise) * 3 - 1, labels {0,1}).  x (n,2) f32, k (n) int64; the permutation is the caller's. */
+int mmb_toy_sample(int kind, int64_t n, int V, float noise, uint64_t seed, uint64_t offset, float* x, int64_t* k,
+                   void* stream);
 
 #ifdef __cplusplus
 }

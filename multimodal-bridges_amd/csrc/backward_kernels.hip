@@ -37,6 +37,9 @@ __device__ inline float act_grad(int act, float ref) {
   }
   if (act == MMB_ACT_LRELU) return ref > 0.0f ? 1.0f : 0.01f;
   if (act == MMB_ACT_RELU) return ref > 0.0f ? 1.0f : 0.0f;
+  if (act == MMB_ACT_SELU)          // ref = the OUTPUT y (same sign as z): y > 0 -> scale, else scale*alpha*exp(z) = y + scale*alpha
+    return ref > 0.0f ? 1.0507009873554804934193349852946f
+                      : ref + 1.0507009873554804934193349852946f * 1.6732632423543772848170429916717f;
   return 1.0f;
 }
 
@@ -524,10 +527,11 @@ extern "C" int mmb_act_bwd(int64_t M, int Nout, const float* gY1, int64_t gY1_ld
                            uint64_t seed, uint64_t offset, float* dZ, int64_t dz_ld, void* stream) {
   MMB_REQUIRE(M > 0 && Nout > 0, "mmb_act_bwd: empty shape");
   MMB_REQUIRE(dZ && (gY1 || gY2), "mmb_act_bwd: need dZ and at least one incoming gradient");
-  MMB_REQUIRE(act >= 0 && act <= 3 && post >= 0 && post <= 3, "mmb_act_bwd: bad activation");
+  MMB_REQUIRE(act >= 0 && act <= 4 && post >= 0 && post <= 3, "mmb_act_bwd: bad activation");
   if (gY2 && post != MMB_ACT_NONE) MMB_REQUIRE(y1 || y2, "mmb_act_bwd: post activation needs y1 or y2");
   if (act == MMB_ACT_GELU) MMB_REQUIRE(pre, "mmb_act_bwd: GELU needs the pre-activation");
   if (act == MMB_ACT_LRELU || act == MMB_ACT_RELU) MMB_REQUIRE(pre || y1, "mmb_act_bwd: (leaky-)relu needs pre or y1");
+  if (act == MMB_ACT_SELU) MMB_REQUIRE(y1 && !pre, "mmb_act_bwd: SELU takes its derivative from the output y1 (no residual on it)");
   ActBwd a{gY1, gY2, y1, y2, res2, pre, gY1_ld, gY2_ld, y1_ld, y2_ld, res2_ld, pre_ld, dz_ld, act, post, drop_p, seed, offset};
   hipLaunchKernelGGL(act_bwd_kernel, dim3(stream_grid(M * Nout, 256)), dim3(256), 0, as_stream(stream), M, Nout, a, dZ);
   return check_launch("mmb_act_bwd");

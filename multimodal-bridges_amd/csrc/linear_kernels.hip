@@ -60,6 +60,9 @@ __device__ inline float apply_act(int act, float x) {
   if (act == MMB_ACT_GELU) return gelu_exact(x);
   if (act == MMB_ACT_LRELU) return x > 0.0f ? x : 0.01f * x;
   if (act == MMB_ACT_RELU) return x > 0.0f ? x : 0.0f;
+  if (act == MMB_ACT_SELU)          // torch.nn.SELU: scale * (max(0,x) + min(0, alpha * (exp(x) - 1)))
+    return x > 0.0f ? 1.0507009873554804934193349852946f * x
+                    : (1.0507009873554804934193349852946f * 1.6732632423543772848170429916717f) * (expf(x) - 1.0f);
   return x;
 }
 
@@ -525,13 +528,13 @@ extern "C" int mmb_linear_cat(int M, int rows_per_jet, int n_seg, const void* co
                               int64_t res2_ld, float* Y2, int64_t y2_ld, void* stream) {
   MMB_REQUIRE(M > 0 && Nout > 0, "mmb_linear_cat: empty shape M=%d Nout=%d", M, Nout);
   MMB_REQUIRE(Y || Y2, "mmb_linear_cat: no output given");
-  MMB_REQUIRE(post_act >= 0 && post_act <= 3, "mmb_linear_cat: bad post activation %d", post_act);
+  MMB_REQUIRE(post_act >= 0 && post_act <= 3, "mmb_linear_cat: bad post activation %d", post_act);   // (SELU: first stage only)
   MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_linear_cat: dropout p=%f outside [0,1)", drop_p);
   Post post{Y2, y2_ld, res2, res2_ld, post_act, drop_p, seed, offset};
   MMB_REQUIRE(rows_per_jet > 0, "mmb_linear_cat: rows_per_jet must be > 0");
   MMB_REQUIRE(n_seg >= 1 && n_seg <= 4, "mmb_linear_cat: n_seg=%d outside [1,4]", n_seg);
   MMB_REQUIRE(seg_ptr && seg_width && seg_kind && seg_ld && W, "mmb_linear_cat: NULL argument");
-  MMB_REQUIRE(act >= 0 && act <= 3, "mmb_linear_cat: bad activation %d", act);
+  MMB_REQUIRE(act >= 0 && act <= 4, "mmb_linear_cat: bad activation %d", act);
   Segs sg;
   sg.n = n_seg;
   int K = 0;

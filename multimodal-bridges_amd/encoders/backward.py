@@ -117,6 +117,8 @@ def _produced(tape):
             keys.add(k(e[2]))
         elif e[0] == "cat":
             keys.add(k(e[2]))
+        elif e[0] == "toyin":
+            keys.add(k(e[3]))
         elif e[0] == "embed":
             keys.add(k(e[4]))
             if e[5] is not None:
@@ -325,7 +327,7 @@ def run_backward(model, tape, heads, d_hc, d_hd, d_s=None, scale=None):
     if d_hd is not None:
         store.seed(heads.discrete, d_hd.reshape(-1, d_hd.shape[-1]))
     produced = _produced(tape)
-    mi = next(e[3] for e in tape if e[0] == "embed")
+    mi = next(e[3] if e[0] == "embed" else e[2] for e in tape if e[0] in ("embed", "toyin"))
     seed = model.seed
     n_acc = sum(GW_REPLICAS * (e[1].weight_v.numel() + e[1].weight_v.shape[0] + 8) for e in tape if e[0] == "linear")
     n_acc += sum(GW_REPLICAS * (e[1].dim_out * (e[1].K + 1) + 8) for e in tape if e[0] == "plinear")
@@ -356,6 +358,13 @@ def run_backward(model, tape, heads, d_hc, d_hd, d_s=None, scale=None):
                     o += w
         elif kind == "embed":
             _embed_bwd(e, store, mi)
+        elif kind == "toyin":                           # input rows [t, x, embed(k)] of the toy MLP: nn.Embedding's gradient
+            _, enc, _mi, rows, k_rows, col0 = e
+            g = store.get(rows)
+            if g is not None:
+                d_table = torch.zeros_like(enc.embed.weight)
+                ops.toy_embedding_bwd(k_rows, g, col0, d_table)
+                _acc_param(enc.embed.weight, d_table)
     lw = getattr(model.loss_multimode, "loss_weights", None)
     if d_s is not None and isinstance(lw, torch.nn.Parameter):
         _acc_param(lw, d_s)

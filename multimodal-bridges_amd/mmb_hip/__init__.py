@@ -104,6 +104,10 @@ SIGNATURES = {
     "mmb_sum_replicas": [C.c_int64, C.c_int, C.c_int64, c_f32p, c_f32p, C.c_int, c_stream],
     "mmb_adamw_clip_step": [C.c_int64, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_float, C.c_float,
                             C.c_float, C.c_float, C.c_int64, C.c_float, c_f32p, c_f32p, C.c_int, c_stream],
+    "mmb_toy_rows": [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, c_i64p, c_f32p, c_f32p,
+                     c_stream],
+    "mmb_toy_embedding_bwd": [C.c_int64, C.c_int, C.c_int, c_i64p, c_f32p, C.c_int64, C.c_int, c_f32p, c_stream],
+    "mmb_toy_sample": [C.c_int, C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_uint64, c_f32p, c_i64p, c_stream],
     "mmb_grad_weight": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
                         C.POINTER(C.c_int), c_f32p, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p, c_stream],
 }
@@ -127,6 +131,8 @@ def lib():
         h.mmb_last_error.restype = C.c_char_p
         h.mmb_last_error.argtypes = []
         for name, args in SIGNATURES.items():
+            if "MMB_LIB_NAME" in os.environ and not hasattr(h, name):
+                continue                    # developer A/B build that predates an entry point (never the shipped library)
             fn = getattr(h, name)
             fn.argtypes = args
             fn.restype = C.c_int

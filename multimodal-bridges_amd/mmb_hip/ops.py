@@ -11,7 +11,7 @@ from . import call, MMBError
 THERMOSTATS = {"ConstantThermostat": 0, "InverseThermostat": 1, "LinearThermostat": 2,
                "InverseSquareThermostat": 3, "SigmoidThermostat": 4}
 BRIDGES = {"UniformFlow": 0, "SchrodingerBridge": 1}
-ACT = {None: 0, "none": 0, "gelu": 1, "lrelu": 2, "relu": 3}
+ACT = {None: 0, "none": 0, "gelu": 1, "lrelu": 2, "relu": 3, "selu": 4}
 SEG_ROW, SEG_JET, SEG_JET_MASK = 0, 1, 2
 
 
@@ -581,3 +581,33 @@ def adamw_clip_step_(params, grads, exp_avg, exp_avg_sq, n_active, lr, betas, ep
          f32(exp_avg, "exp_avg"), f32(exp_avg_sq, "exp_avg_sq"), _fl(lr), _fl(betas[0]), _fl(betas[1]), _fl(eps),
          _fl(weight_decay), int(step), _fl(max_norm or 0.0), f32(partials, "partials"), f32(norm_out, "norm_out"),
          int(bool(write_clipped)), stream())
+
+
+# ------------------------------------------------------------------------ toy config (S1)
+def toy_rows(t, x, k, table, N):
+    """rows (P, 1+Dc+E) = [t(jet), x, table[k]]: the input of the toy MLP (data_toys.ipynb cell 3).
+    t: (B,) per jet or a 1-element tensor for every jet; x (P,Dc); k (P,) int64; table (V,E)."""
+    P, Dc = x.shape
+    V, E = table.shape
+    rows = torch.empty(P, 1 + Dc + E, dtype=torch.float32, device=x.device)
+    call("mmb_toy_rows", P, N, Dc, E, V, f32(t, "t"), 0 if t.numel() == 1 else 1, f32(x, "x"), i64(k, "k"),
+         f32(table, "table"), f32(rows), stream())
+    return rows
+
+
+def toy_embedding_bwd(k, d_rows, col0, d_table):
+    """d_table[k[p], :] += d_rows[p, col0:col0+E]"""
+    V, E = d_table.shape
+    if d_rows.stride(1) != 1:
+        raise MMBError("toy_embedding_bwd: d_rows must have unit inner stride")
+    call("mmb_toy_embedding_bwd", k.numel(), E, V, i64(k, "k"), d_rows.data_ptr(), d_rows.stride(0), col0,
+         f32(d_table, "d_table"), stream())
+    return d_table
+
+
+def toy_sample(kind, n, device, V=8, noise=0.2, seed=0, offset=0):
+    """kind 0: NGaussians, 1: TwoMoons (distributions/toys.py) -> x (n,2) f32, k (n,) int64, in index order."""
+    x = torch.empty(n, 2, dtype=torch.float32, device=device)
+    k = torch.empty(n, dtype=torch.int64, device=device)
+    call("mmb_toy_sample", kind, n, V, _fl(noise), seed, offset, f32(x), i64(k), stream())
+    return x, k

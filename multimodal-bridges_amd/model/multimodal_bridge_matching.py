@@ -77,7 +77,10 @@ class MultiModalBridgeMatching(nn.Module):
     def __init__(self, config):
         super().__init__()
         self.config = config
-        self.embedder = MultiModalEmbedder(config)
+        # an encoder class with `raw_state = True` (the toy MultiModalMLP) takes the bridge state as it is: no embedder
+        self.raw_state = bool(getattr(Encoder[config.encoder.name], "raw_state", False))
+        if not self.raw_state:
+            self.embedder = MultiModalEmbedder(config)
         self.encoder = Encoder[config.encoder.name](config)
         self.modality = config.data.modality
         self.vocab_size = config.data.vocab_size
@@ -130,7 +133,7 @@ class MultiModalBridgeMatching(nn.Module):
 
     def _fused_pack(self):
         """Packed parameters of the fused per-jet kernels, rebuilt when a parameter changed."""
-        if not self.use_fused:
+        if not self.use_fused or self.raw_state:
             return None
         ver = fused_epic.params_version(self)
         if self._fused_cache is None:
@@ -169,6 +172,8 @@ class MultiModalBridgeMatching(nn.Module):
         """Embedder + encoder.  `which` names the head the caller consumes; the generic layered
         path always evaluates both (the fused generation kernel honours it)."""
         mi = self._mask_info(state)
+        if self.raw_state:
+            return self.encoder(state, None, tape=self._tape, seed=self.seed)
         t = getattr(state, "_t_scalar", None)
         time = state.time if t is None else t
         inference = self._tape is None and (not self.training or not self.config.encoder.dropout)

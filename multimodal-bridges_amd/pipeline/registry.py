@@ -9,16 +9,20 @@ from model.thermostats import (ConstantThermostat, InverseThermostat, LinearTher
                                SigmoidThermostat)
 from encoders.multimodal_epic import UniModalEPiC, MultiModalEPiC
 from encoders.particle_transformer import MultiModalParticleTransformer
+from encoders.mlp import MultiModalMLP
+from distributions.toys import NGaussians, TwoMoons
 
 registered_datasets = {}          # AspenOpenJets HDF5 reader: outside the hot path
 
-registered_distributions = {"SourceUniform": SourceUniform}
+registered_distributions = {"SourceUniform": SourceUniform,
+                            "NGaussians": NGaussians, "TwoMoons": TwoMoons}     # toys.py (not registered upstream: torchdyn)
 
 registered_bridges = {"UniformFlow": UniformFlow, "SchrodingerBridge": SchrodingerBridge,
                       "TelegraphBridge": TelegraphBridge}
 
 registered_models = {"UniModalEPiC": UniModalEPiC, "MultiModalEPiC": MultiModalEPiC,
-                     "MultiModalParticleTransformer": MultiModalParticleTransformer}
+                     "MultiModalParticleTransformer": MultiModalParticleTransformer,
+                     "MultiModalMLP": MultiModalMLP}      # the toy notebook's class (data_toys.ipynb cell 3)
 
 registered_thermostats = {"ConstantThermostat": ConstantThermostat, "LinearThermostat": LinearThermostat,
                           "InverseThermostat": InverseThermostat,

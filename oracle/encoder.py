@@ -232,8 +232,27 @@ def multimodal_transformer(p, loc_time, loc_cont, loc_disc, mask, nheads, prefix
     return hc, hd
 
 
+def multimodal_mlp(p, time, continuous, discrete, prefix="encoder"):
+    """MultiModalMLP.forward of notebooks/data_toys.ipynb cell 3 (the toy experiment's network; takes the raw state):
+    h = body(cat[time, x, embed(k)]) with body = Linear, SELU, Linear, SELU, Linear, SELU, Linear; two Linear heads.
+    Written for (B,N,.) states (the notebook has N = 1 and squeezes that axis); time (B,1,1), (B,1) or (B,)."""
+    B, N = discrete.shape[0], discrete.shape[1]
+    t = time.reshape(B, -1)[:, :1].reshape(B, 1, 1).expand(B, N, 1)
+    emb = F.embedding(discrete.reshape(B, N).long(), p[prefix + ".embed.weight"])
+    h = torch.cat([t, continuous, emb], dim=-1)
+    for i in (0, 2, 4, 6):
+        h = F.linear(h, p[f"{prefix}.body.{i}.weight"], p[f"{prefix}.body.{i}.bias"])
+        if i < 6:
+            h = F.selu(h)
+    hc = F.linear(h, p[prefix + ".continous_head.weight"], p[prefix + ".continous_head.bias"])
+    hd = F.linear(h, p[prefix + ".discrete_head.weight"], p[prefix + ".discrete_head.bias"])
+    return hc, hd
+
+
 def forward(p, time, continuous, discrete, mask, encoder_name="MultiModalEPiC", skip=True, num_heads=None):
     """multimodal_bridge_matching.py:73-75 -> (head_continuous | None, head_discrete | None)."""
+    if encoder_name == "MultiModalMLP":
+        return multimodal_mlp(p, time, continuous, discrete)
     lt, lc, ld, gt = embedder(p, time, continuous, discrete, mask)
     if encoder_name == "MultiModalEPiC":
         return multimodal_epic(p, lt, lc, ld, gt, mask, skip)

@@ -495,6 +495,103 @@ def golden_model(name, cfg, B, N, mask_kind, store_params, seed=3, steps_list=(1
     npz_save("model_" + name, **out)
 
 
+def golden_toy(name="toy", B=48, seed=21, steps_list=(10, 100)):
+    """S1 (BASELINE configs[0]): the toy notebook's MultiModalMLP -- its class definition is executed from
+    notebooks/data_toys.ipynb cell 3 where it lies -- inside the reference's MultiModalBridgeMatching (bridges, loss_fn,
+    MultiModeLoss, solvers, simulate_dynamics) at N = 1, Dc = 2, V = 8.  Harness glue only: an identity embedder (the
+    notebook network takes the raw state) and an adapter that gives the MLP the (B,1,1) time it squeezes and returns
+    (B,1,.) heads.  Source / target points come from oracle.toys (toys.py needs torchdyn, absent here)."""
+    import contextlib
+    import io
+    from torch import nn
+    from tensorclass import TensorMultiModal
+    from datamodules.datasets import DataCoupling
+    from oracle import toys as OT
+    print(f"[{name}] B={B}")
+    with open(REF + "/notebooks/data_toys.ipynb") as fh:
+        nb = json.load(fh)
+    ns = {"TensorMultiModal": TensorMultiModal}
+    with contextlib.redirect_stdout(io.StringIO()):
+        exec(compile("".join(nb["cells"][3]["source"]), "data_toys.ipynb[3]", "exec"), ns)
+    MLP = ns["MultiModalMLP"]
+
+    class Adapter(MLP):
+        def forward(self, state_local, state_global=None):
+            Bn = state_local.discrete.shape[0]
+            st = TensorMultiModal(state_local.time.reshape(Bn, 1, 1), state_local.continuous, state_local.discrete,
+                                  state_local.mask)
+            with contextlib.redirect_stdout(io.StringIO()):          # the notebook class prints shapes
+                h = MLP.forward(self, st)
+            return TensorMultiModal(None, h.continuous.unsqueeze(1), h.discrete.unsqueeze(1), state_local.mask)
+
+    class Ident(nn.Module):
+        def forward(self, state, batch):
+            return state, None
+
+    ref_cfg = base_cfg()
+    ref_cfg["data"].update(max_num_particles=1, continuous_features=["x", "y"])
+    ref_cfg["model"].update(gamma=0.075, loss_weights="fixed")
+    cfg = copy.deepcopy(ref_cfg)                  # what THIS repo's model is built from
+    cfg["encoder"] = {"name": "MultiModalMLP", "num_blocks": 4, "dim_hidden_local": 64, "skip_connection": False,
+                      "dropout": 0.0, "dim_emb_time": 1}
+    cfg["data"].update(target_name="TwoMoons", source_name="NGaussians")
+    model = build_model(ref_cfg, seed)
+    model.embedder = Ident()
+    model.encoder = Adapter(dim=2, vocab_size=8, dim_hidden=64)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(synth_param(n, p.shape, seed))
+    model.eval()
+    V = 8
+    g = torch.Generator().manual_seed(100 + seed)
+    x1, k1 = OT.two_moons(B, generator=g)
+    x0, k0 = OT.n_gaussians(B, generator=g)
+    mask = torch.ones(B, 1, 1, dtype=torch.int64)
+    out = {"cfg_json": json.dumps(cfg), "flat_cfg_json": json.dumps(flat_cfg(cfg)), "seed": seed,
+           "param_names": json.dumps([n for n, _ in model.named_parameters()]),
+           "param_shapes": json.dumps([list(p.shape) for _, p in model.named_parameters()]),
+           "mask": mask, "k1": k1, "x1": x1, "x0": x0, "k0": k0}
+    for n, p in model.named_parameters():
+        out["param:" + n] = p.detach()
+    mk = lambda x, k: TensorMultiModal(None, x.clone(), k.clone(), mask.clone())
+    batch = DataCoupling(mk(x0, k0), mk(x1, k1), None)
+    torch.manual_seed(555 + seed)
+    with Tape(V) as tape:
+        state = model.sample_bridges(batch)
+    out["t_u"] = tape.rec["rand"][0]
+    out["z"] = tape.rec["randn_like"][0]
+    out["xt"], out["kt"], out["time"] = state.continuous, state.discrete, state.time
+    out["u_k"] = tape.rec["u_cat"][0].reshape(B, 1)
+    out["u_k_margin"] = tape.rec["cat_margin"][0].reshape(B, 1)
+    model.zero_grad()
+    heads = model.forward(state, batch)
+    lc, ld = model.loss_fn(heads, state, batch)
+    loss = model.loss_multimode([lc, ld])
+    loss.backward()
+    out["head_continuous"], out["head_discrete"] = heads.continuous, heads.discrete
+    out["loss"], out["loss_continuous"], out["loss_discrete"] = loss, lc, ld
+    gnorm2 = 0.0
+    for n, p in model.named_parameters():
+        out["grad:" + n] = p.grad
+        gnorm2 += float((p.grad.double() ** 2).sum())
+    out["grad_norm"] = np.float64(gnorm2 ** 0.5)
+    for steps in steps_list:
+        model.config.model.num_timesteps = steps
+        gs = torch.Generator().manual_seed(4242 + seed + steps)
+        sx, sk = OT.n_gaussians(B, generator=gs)
+        batch = DataCoupling(mk(sx, sk), mk(x1, k1), None)
+        torch.manual_seed(777 + seed + steps)
+        with Tape(V) as tape, torch.no_grad():
+            paths, _ = model.predict_step(batch, 0)
+        tag = f"gen{steps}"
+        out[tag + ":src_mask"], out[tag + ":src_k"], out[tag + ":src_x"] = paths.mask[0], paths.discrete[0], paths.continuous[0]
+        out[tag + ":final_k"], out[tag + ":final_x"] = paths.discrete[1], paths.continuous[1]
+        dn = torch.stack(tape.rec["poisson"], 0)
+        assert dn.max() < 65535
+        out[tag + ":delta_n"] = dn.numpy().astype(np.uint16)
+    npz_save("model_" + name, **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
@@ -521,7 +618,13 @@ def main():
     golden_model("tr_tiny", V["tr_tiny"], 4, 16, "random_full", True, seed=11, explicit_source=True)
     golden_model("tr_odd", V["tr_odd"], 3, 11, "random_full", True, seed=12, explicit_source=True)
     golden_model("S4", V["S4"], 2, 150, "random_full", False, seed=13, steps_list=(5,), explicit_source=True)
+    golden_toy()
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "toy":       # regenerate one fixture without touching the others
+        _install_stubs()
+        torch.set_num_threads(8)
+        golden_toy()
+    else:
+        main()

@@ -503,6 +503,15 @@ int mmb_toy_embedding_bwd(int64_t P, int E, int V, const int64_t* k, const float
 int mmb_toy_sample(int kind, int64_t n, int V, float noise, uint64_t seed, uint64_t offset, float* x, int64_t* k,
                    void* stream);
 
+/* ---------------------------------------------------------------- AspenOpenJets reader */
+/* AspenOpenJets._read_aoj_file's arithmetic (datamodules/aoj.py:147-245) on a raw PFCands block (J,M,F) f32, pid at
+ * column F-2: rows with |pid| < 11 are zeroed (_filter_particles :179-184); feats (J,M,3) = (pt, eta_rel, phi_rel)
+ * relative to the jet axis (the summed four-vector), times mask (_compute_continuous_coordinates :202-233);
+ * tokens (J,M) = the 8-token flavour x charge map, unknown pids -> 0 (_map_pid_to_tokens :186-200);
+ * mask (J,M) = (E > 0) (:222). */
+int mmb_aoj_features(int J, int M, int F, const float* pfcands, float* feats, int64_t* tokens, int64_t* mask,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -611,3 +611,14 @@ def toy_sample(kind, n, device, V=8, noise=0.2, seed=0, offset=0):
     k = torch.empty(n, dtype=torch.int64, device=device)
     call("mmb_toy_sample", kind, n, V, _fl(noise), seed, offset, f32(x), i64(k), stream())
     return x, k
+
+
+# ------------------------------------------------------------------------ AOJ reader
+def aoj_features(pfcands):
+    """raw PFCands (J,M,F) f32 on device -> (feats (J,M,3) = pt, eta_rel, phi_rel; tokens (J,M,1) i64; mask (J,M,1) i64)"""
+    J, M, F = pfcands.shape
+    feats = torch.empty(J, M, 3, dtype=torch.float32, device=pfcands.device)
+    tokens = torch.empty(J, M, 1, dtype=torch.int64, device=pfcands.device)
+    mask = torch.empty(J, M, 1, dtype=torch.int64, device=pfcands.device)
+    call("mmb_aoj_features", J, M, F, f32(pfcands, "pfcands"), f32(feats), i64(tokens), i64(mask), stream())
+    return feats, tokens, mask

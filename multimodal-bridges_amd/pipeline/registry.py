@@ -12,7 +12,9 @@ from encoders.particle_transformer import MultiModalParticleTransformer
 from encoders.mlp import MultiModalMLP
 from distributions.toys import NGaussians, TwoMoons
 
-registered_datasets = {}          # AspenOpenJets HDF5 reader: outside the hot path
+from datamodules.aoj import AspenOpenJets
+
+registered_datasets = {"AspenOpenJets": AspenOpenJets}     # datamodules/aoj.py
 
 registered_distributions = {"SourceUniform": SourceUniform,
                             "NGaussians": NGaussians, "TwoMoons": TwoMoons}     # toys.py (not registered upstream: torchdyn)

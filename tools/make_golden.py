@@ -592,6 +592,62 @@ def golden_toy(name="toy", B=48, seed=21, steps_list=(10, 100)):
     npz_save("model_" + name, **out)
 
 
+def synth_pfcands(J, M, F=10, seed=31):
+    """AOJ-shaped raw PFCands block (J,M,F) f32: columns px,py,pz,E,d0,d0Err,dz,dzErr,pid,puppi; a jet-like
+    collimated spray around a random axis, pids from the AOJ flavour mix plus a few the reference filters out
+    (|pid| < 11), unknown ones (pid 310) and zero padding."""
+    r = np.random.default_rng(seed)
+    pf = np.zeros((J, M, F), dtype=np.float32)
+    pids = np.array([22, 130, -211, 211, -11, 11, -13, 13, 310, 1, 2], dtype=np.float32)
+    prob = np.array([0.30, 0.08, 0.29, 0.29, 0.005, 0.005, 0.005, 0.005, 0.01, 0.005, 0.005])
+    prob = prob / prob.sum()
+    for j in range(J):
+        n = int(r.integers(1, M + 1)) if j else M                   # jet 0 is full
+        jeta, jphi = r.uniform(-2, 2), r.uniform(-np.pi, np.pi)
+        pt = r.exponential(20.0, n).astype(np.float32) + 0.5
+        eta = (jeta + 0.3 * r.standard_normal(n)).astype(np.float32)
+        phi = (jphi + 0.3 * r.standard_normal(n)).astype(np.float32)
+        pf[j, :n, 0] = pt * np.cos(phi)
+        pf[j, :n, 1] = pt * np.sin(phi)
+        pf[j, :n, 2] = pt * np.sinh(eta)
+        pf[j, :n, 3] = pt * np.cosh(eta)
+        pf[j, :n, 4:8] = r.standard_normal((n, 4)).astype(np.float32)
+        pf[j, :n, 8] = r.choice(pids, n, p=prob)
+        pf[j, :n, 9] = 1.0
+    pf[1, 0, :4] = 0.0                                              # a candidate with pt = 0 and E = 0 but a valid pid
+    pf[2, 1, 0:2] = 0.0                                             # pt = 0, pz and E kept: the `where=pt != 0` branch
+    return pf
+
+
+def golden_aoj():
+    """the reference's AspenOpenJets arithmetic (datamodules/aoj.py) on a synthetic PFCands block --
+    everything of _read_aoj_file after the h5py read, _preprocess for the three transforms, _extract_metadata."""
+    from datamodules.aoj import AspenOpenJets
+    print("[aoj]")
+    aoj = AspenOpenJets(data_dir="/nonexistent", data_files=None)
+    J, M = 24, 30
+    raw = synth_pfcands(J, M)
+    out = {"pfcands": raw}
+    pf = aoj._filter_particles(raw.copy())
+    feats, mask = aoj._compute_continuous_coordinates(pf)
+    tokens = aoj._map_pid_to_tokens(pf[:, :, -2])[:, :, None]
+    for k in ("pt", "eta_rel", "phi_rel"):
+        out["feat:" + k] = feats[k].astype(np.float32)
+    out["tokens"] = tokens.astype(np.int64)
+    out["mask"] = mask.astype(np.int64)
+    cont = torch.cat([torch.tensor(feats[k], dtype=torch.float32) for k in ("pt", "eta_rel", "phi_rel")], dim=-1)
+    disc = torch.tensor(tokens, dtype=torch.float32)
+    mk = torch.tensor(mask[:, :, None], dtype=torch.long)
+    for tr in ("none", "standardize", "normalize", "log_pt"):
+        torch.manual_seed(90)
+        with Tape(8) as tape:
+            c, d, m, md = aoj._preprocess(cont.clone(), disc.clone(), mk.clone(), None if tr == "none" else tr)
+        out[f"pre:{tr}:perm"] = tape.rec["randperm"][0]
+        out[f"pre:{tr}:continuous"], out[f"pre:{tr}:discrete"], out[f"pre:{tr}:mask"] = c, d, m
+        out[f"pre:{tr}:metadata_json"] = json.dumps(md)
+    npz_save("aoj", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
@@ -619,6 +675,7 @@ def main():
     golden_model("tr_odd", V["tr_odd"], 3, 11, "random_full", True, seed=12, explicit_source=True)
     golden_model("S4", V["S4"], 2, 150, "random_full", False, seed=13, steps_list=(5,), explicit_source=True)
     golden_toy()
+    golden_aoj()
 
 
 if __name__ == "__main__":
@@ -626,5 +683,8 @@ if __name__ == "__main__":
         _install_stubs()
         torch.set_num_threads(8)
         golden_toy()
+    elif len(sys.argv) > 1 and sys.argv[1] == "aoj":
+        _install_stubs()
+        golden_aoj()
     else:
         main()

@@ -1,14 +1,16 @@
-"""Summarise the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (gpurun_out/pmc_<tag>/{fetch,write}_<WL>/)
-into profiles/r1/<tag>_pmc_summary.json and refresh profiles/r1/pmc_traffic.json (FETCH doubled per MI355X_MICROARCH.md).
-usage: python tools/pmc_summary.py <tag>"""
-import collections, csv, json, sys
+"""Summarise the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (tools/profile_round.sh <tag> ->
+gpurun_out/prof_<tag>/{fetch,write}_<WL>/) into profiles/<round>/<tag>_pmc_summary.json and refresh
+profiles/<round>/pmc_traffic.json (FETCH doubled per MI355X_MICROARCH.md).
+usage: python tools/pmc_summary.py <tag> [round dir, default r2]"""
+import collections, csv, json, os, sys
 
 tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r2"
 out = {}
 for wl in ("S3", "S2"):
     for kind in ("fetch", "write"):
         agg = collections.defaultdict(list)
-        with open(f"gpurun_out/pmc_{tag}/{kind}_{wl}/p_counter_collection.csv") as fh:
+        with open(f"gpurun_out/prof_{tag}/{kind}_{wl}/p_counter_collection.csv") as fh:
             for r in csv.DictReader(fh):
                 name = r["Kernel_Name"]
                 if "mmb::" not in name:
@@ -19,9 +21,9 @@ for wl in ("S3", "S2"):
                 agg[short].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             out.setdefault(wl, {}).setdefault(k, {})[kind] = (sum(v) / len(v), len(v))
-json.dump(out, open(f"profiles/r1/{tag}_pmc_summary.json", "w"), indent=1)
-p = "profiles/r1/pmc_traffic.json"
-d = json.load(open(p))
+json.dump(out, open(f"profiles/{rnd}/{tag}_pmc_summary.json", "w"), indent=1)
+p = f"profiles/{rnd}/pmc_traffic.json"
+d = json.load(open(p)) if os.path.exists(p) else {}
 gen = {"S3": "fused_generate_kernel", "S2": "fused_uni_generate_kernel"}
 step = {}
 for wl in ("S3", "S2"):
@@ -39,5 +41,5 @@ for wl in ("S3", "S2"):
     step[wl] = {"bytes_per_step": tot, "kernels": det}
     print(wl, "generation launch", d[wl], "training step", tot)
 d["training_step"] = step
-d["_source"] = f"profiles/r1/{tag}_pmc_summary.json"
+d["_source"] = f"profiles/{rnd}/{tag}_pmc_summary.json"
 json.dump(d, open(p, "w"), indent=1)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: generated jets/s @128 particles, 100 solver steps (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S3|S2|S5|S4] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S3|S2|S5|S4|S1] [--batch B]
 
 One "step" = one full pass of the generation hot path over one batch of synthetic
 AOJ-shaped clouds per rank: on-device SourceUniform draw (multiplicity masks from the AOJ
@@ -44,7 +44,8 @@ PEAK_BF16_MFMA_TFLOPS = 2516.8     # same guide: v_mfma_f32_32x32x16_bf16, dense
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {"S3": "configs/S3_multimodal.yaml", "S2": "configs/S2_discrete.yaml",
-             "S5": "configs/S5_large_generation.yaml", "S4": "configs/S4_transformer.yaml"}
+             "S5": "configs/S5_large_generation.yaml", "S4": "configs/S4_transformer.yaml",
+             "S1": "configs/S1_toy.yaml"}
 
 
 def build_model(workload, steps_per_gen, device):
@@ -339,7 +340,8 @@ def main():
                     "launches": dom["n"], "avg_launch_us": dom["ms"] * 1e3 / dom["n"],
                     "share_of_gpu_time": dom["ms"] / total_ms}
         line = {
-            "metric": f"generated jets/sec @128 particles, {args.solver_steps} steps", "value": value, "unit": "jets/s",
+            "metric": f"generated jets/sec @{config.data.max_num_particles} particles, {args.solver_steps} steps",
+            "value": value, "unit": "jets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -12,6 +12,7 @@ driven by pipeline/experiment.py.  What runs underneath:
 
 Everything returned is a DEVICE tensor; nothing calls .item().
 """
+import sys
 from typing import Dict
 
 import torch
@@ -144,7 +145,7 @@ class MultiModalBridgeMatching(nn.Module):
                 print(f"[mmb] {e.name} with dim_hidden_local={e.dim_hidden_local}, dim_hidden_glob={e.dim_hidden_glob}, "
                       f"dim_emb_time={e.dim_emb_time} is not one of the compiled fused variants "
                       f"(mmb_hip/fused.py: VARIANTS / UNI_VARIANTS; V = 8, Dc = 3, N <= 128): running the layered "
-                      f"HIP path, several times slower in generation and training", flush=True)
+                      f"HIP path, several times slower in generation and training", file=sys.stderr, flush=True)
         elif self._fused_cache[0] != ver:
             old = self._fused_cache[1]
             if old is not None and "gather" in old and old["packed"].device == self.device:

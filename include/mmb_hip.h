@@ -388,11 +388,13 @@ int mmb_sum_replicas(int64_t n, int replicas, int64_t stride, const float* src, 
  * mmb_hip.fused.pack_model (fp32 part: transposed per-jet matrices, time/global parts, biases; after it the
  * weight-normed effective weights of the per-particle layers in MFMA fragment order, each fp32 value split exactly
  * into three bf16 planes hi+mid+lo, [KT][2][OT][3][64 lanes][8 bf16]: the kernels form every fp32 product from
- * six bf16 x bf16 partial products accumulated in fp32, results are fp32 results).  variant 0: S3 widths (Et32 Ec16 Ed16 H64/64/128 G16/16/32); variant 1:
- * Et16 Ec8 Ed8 H32/32/64 G8/8/16.  N <= 128, Dc = 3, V = 8.  temb: (B,Et) with row stride
+ * six bf16 x bf16 partial products accumulated in fp32, results are fp32 results).  Compiled width sets: variant 0: S3
+ * (Et32 Ec16 Ed16 H64/64/128 G16/16/32); 1: Et16 Ec8 Ed8 H32/32/64 G8/8/16; 2: Et64 Ec32 Ed32 H64/64/128 G32/32/64;
+ * 3: Et32 Ec16 Ed16 H32/32/64 G16/16/32.  nb_branch / nb_branch1: EPiC layers of the continuous / discrete branch
+ * encoder (they may differ), nb_fused_exec: executed layers of the fused encoder (K2).  N <= 128, Dc = 3, V = 8.  temb: (B,Et) with row stride
  * temb_stride (0 = one row shared by all jets).  which: 0 continuous head, 1 discrete head, 2 both. */
 int mmb_fused_epic_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
-                           int nb_branch, int nb_fused_exec, int use_skip,
+                           int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip,
                            int off_cw, int off_cb, int off_table,
                            const float* maskf, const int32_t* counts,
                            const float* x, const int64_t* k, const float* temb, int64_t temb_stride,
@@ -408,7 +410,7 @@ int mmb_fused_epic_forward(int variant, int B, int N, const float* packed, const
  * input behind register r of tile t); output], the concatenated global vector, fused encoder [layers; output], heads [.0 pre/out] x 2.
  * head_c (B*N,3), head_d (B*N,8). */
 int mmb_fused_epic_train_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
-                                 int nb_branch, int nb_fused_exec, int use_skip,
+                                 int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip,
                                  int off_cw, int off_cb, int off_table,
                                  const float* maskf, const int32_t* counts,
                                  const float* x, const int64_t* k, const float* temb, int64_t temb_stride,
@@ -427,7 +429,7 @@ int mmb_fused_epic_train_forward(int variant, int B, int N, const float* packed,
  * per branch the same followed by the projection {global.2 pre, dZ, global.0 pre, dZ, local.2 pre, dZ, local.0 pre,
  * dZ, column sums} and, for the continuous branch, d (continuous embedding) (rows,Ec). */
 int mmb_fused_epic_train_backward(int variant, int B, int N, const float* packed_bwd, const int32_t* desc_bwd,
-                                  int nb_branch, int nb_fused_exec, int use_skip,
+                                  int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip,
                                   const float* maskf, const int32_t* counts,
                                   const void* slots, int n_slots, float drop_p, uint64_t seed, uint64_t offset0,
                                   void* stream);
@@ -458,7 +460,7 @@ int mmb_fused_uni_train_backward(int variant, int B, int N, const float* packed_
  * sigma_t = em_sigma*sqrt(t(1-t)), NO sqrt(dt)): x += dt v + sigma_t dW with dW from delta_w
  * (steps,B,N,3) or, when NULL, Philox + Box-Muller. */
 int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, const int32_t* desc,
-                            int nb_branch, int nb_fused_exec, int use_skip,
+                            int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip,
                             int off_cw, int off_cb, int off_table,
                             const float* maskf, const int32_t* counts, float* x, int64_t* k,
                             int steps, const float* times, const float* temb_steps,
@@ -470,7 +472,8 @@ int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, cons
 /* UniModalEPiC (discrete-only model): MultiModalBridgeMatching.forward with
  * encoders/multimodal_epic.py:44-64 (+ embedder.py:74-80, epic.py:71-98) for one jet per workgroup.
  * The projection sees cat[t, t, trunc(k_emb*mask)]; both time blocks are summed on the host.
- * variant 0: Et128 Ed128 H128 G16 (configs/S2_discrete.yaml); variant 1: Et16 Ed16 H32 G8.
+ * variant 0: Et128 Ed128 H128 G16 (configs/S2_discrete.yaml); 1: Et16 Ed16 H32 G8; 2: Et64 Ed64 H64 G16;
+ * 3: Et32 Ed32 H32 G16.
  * N <= 128, V = 8.  head_d: (B,N,8) logits. */
 int mmb_fused_uni_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
                           int num_blocks, int use_skip, int off_table,

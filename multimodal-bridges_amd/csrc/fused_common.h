@@ -554,8 +554,14 @@ struct Dims {
   static constexpr int GF = 2 * GB;
 };
 
-typedef Dims<32, 16, 16, 64, 16, 3, 8> DimsS3;       // configs/S3_multimodal.yaml
-typedef Dims<16, 8, 8, 32, 8, 3, 8> DimsMid;         // the mm_mid golden / small models
+// The compiled width sets (variant id = position; mmb_hip/fused.py: VARIANTS / UNI_VARIANTS must list the same).
+// Constraints: HB a multiple of 32 and <= 64 (the fused encoder's 2*HB/32 tiles x 2 live in registers), GB a power of
+// two <= 32, ET a power of two <= 128, EC, ED <= 32.
+typedef Dims<32, 16, 16, 64, 16, 3, 8> DimsS3;       // 0: configs/S3_multimodal.yaml
+typedef Dims<16, 8, 8, 32, 8, 3, 8> DimsMid;         // 1: the mm_mid golden / small models
+typedef Dims<64, 32, 32, 64, 32, 3, 8> DimsWide;     // 2: Et64 Ec32 Ed32 H64/64/128 G32/32/64
+typedef Dims<32, 16, 16, 32, 16, 3, 8> DimsNarrow;   // 3: Et32 Ec16 Ed16 H32/32/64 G16/16/32
+constexpr int N_MULTI_VARIANTS = 4;
 
 // discrete-only model (UniModalEPiC): one encoder with projection
 template <int ET_, int ED_, int H_, int G_, int V_>
@@ -566,7 +572,10 @@ struct UniDims {
   static constexpr int EDP = 32 * EDT;            // padded embedding width
 };
 
-typedef UniDims<128, 128, 128, 16, 8> UniS2;         // configs/S2_discrete.yaml
-typedef UniDims<16, 16, 32, 8, 8> UniMid;            // the uni_mid golden
+typedef UniDims<128, 128, 128, 16, 8> UniS2;         // 0: configs/S2_discrete.yaml
+typedef UniDims<16, 16, 32, 8, 8> UniMid;            // 1: the uni_mid golden
+typedef UniDims<64, 64, 64, 16, 8> UniH64;           // 2: Et64 Ed64 H64 G16
+typedef UniDims<32, 32, 32, 16, 8> UniH32;           // 3: Et32 Ed32 H32 G16
+constexpr int N_UNI_VARIANTS = 4;
 
 }  // namespace mmb

@@ -246,6 +246,7 @@ struct FusedArgs {
   int B, N;
   const float* maskf;      // (B,N)
   const int32_t* counts;   // (B)
+  int nb_branch1;          // EPiC layers of the discrete branch (nb_branch: the continuous one); they may differ
 };
 
 // embedded inputs of one particle as padded 32-feature tiles (embedder.py:74-80 + apply_mask)
@@ -292,7 +293,8 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
     if (tid < DM::GB) L.gskip[tid] = L.gcur[tid];
     ffor<HBT>([&](auto t) { sk[decltype(t)::v] = x[decltype(t)::v]; });
     __syncthreads();
-    for (int i = 0; i < A.nb_branch; ++i)
+    const int nbb = br == 0 ? A.nb_branch : A.nb_branch1;
+    for (int i = 0; i < nbb; ++i)
       Epic<HBT, DM::ET, DM::GB>::layer(x, [&](auto t) -> const f32x16& { return sk[decltype(t)::v]; },
                                        A.use_skip != 0, A.P, A.D, li, L, m, tid, A.ctab, ci, tr);
     Epic<HBT, DM::ET, DM::GB>::template output<HBT, DM::HB>(out, x, A.P, A.D, li, L, m, tid, A.ctab, ci, tr);
@@ -791,53 +793,61 @@ using namespace mmb;
 
 // variant: 0 = S3 dims (Et32 Ec16 Ed16 H64/64/128 G16/16/32), 1 = "mid" dims (Et16 Ec8 Ed8 H32/32/64 G8/8/16)
 extern "C" int mmb_fused_epic_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
-                                      int nb_branch, int nb_fused_exec, int use_skip, int off_cw, int off_cb,
+                                      int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip, int off_cw, int off_cb,
                                       int off_table, const float* maskf, const int32_t* counts, const float* x,
                                       const int64_t* k, const float* temb, int64_t temb_stride, int which,
                                       float* head_c, float* head_d, void* stream) {
   int rc = check_fused("mmb_fused_epic_forward", B, N, packed, desc, maskf, counts);
   if (rc) return rc;
-  MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_epic_forward: unknown variant %d", variant);
+  MMB_REQUIRE(variant >= 0 && variant < N_MULTI_VARIANTS, "mmb_fused_epic_forward: unknown variant %d", variant);
   MMB_REQUIRE(x && k && temb, "mmb_fused_epic_forward: NULL state");
   MMB_REQUIRE(which >= 0 && which <= 2, "mmb_fused_epic_forward: which=%d", which);
   if (which != 1) MMB_REQUIRE(head_c, "mmb_fused_epic_forward: head_c is NULL");
   if (which != 0) MMB_REQUIRE(head_d, "mmb_fused_epic_forward: head_d is NULL");
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
-              off_table, B, N, maskf, counts};
+              off_table, B, N, maskf, counts, nb_branch1};
   const int grid = B < 4096 ? B : 4096;
-  if (variant == 0)
-    hipLaunchKernelGGL(fused_forward_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k, temb,
-                       temb_stride, which, head_c, head_d);
-  else
-    hipLaunchKernelGGL(fused_forward_kernel<DimsMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k, temb,
-                       temb_stride, which, head_c, head_d);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL(fused_forward_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k, temb,
+                       temb_stride, which, head_c, head_d); break;
+    case 1: hipLaunchKernelGGL(fused_forward_kernel<DimsMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k, temb,
+                       temb_stride, which, head_c, head_d); break;
+    case 2: hipLaunchKernelGGL(fused_forward_kernel<DimsWide>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k, temb,
+                       temb_stride, which, head_c, head_d); break;
+    default: hipLaunchKernelGGL(fused_forward_kernel<DimsNarrow>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k, temb,
+                       temb_stride, which, head_c, head_d); break;
+  }
   return check_launch("mmb_fused_epic_forward");
 }
 
 extern "C" int mmb_fused_epic_train_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
-                                            int nb_branch, int nb_fused_exec, int use_skip, int off_cw, int off_cb,
+                                            int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip, int off_cw, int off_cb,
                                             int off_table, const float* maskf, const int32_t* counts, const float* x,
                                             const int64_t* k, const float* temb, int64_t temb_stride,
                                             const void* slots, int n_slots, float drop_p, uint64_t seed,
                                             uint64_t offset0, float* head_c, float* head_d, void* stream) {
   int rc = check_fused("mmb_fused_epic_train_forward", B, N, packed, desc, maskf, counts);
   if (rc) return rc;
-  MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_epic_train_forward: unknown variant %d", variant);
+  MMB_REQUIRE(variant >= 0 && variant < N_MULTI_VARIANTS, "mmb_fused_epic_train_forward: unknown variant %d", variant);
   MMB_REQUIRE(x && k && temb && head_c && head_d && slots, "mmb_fused_epic_train_forward: NULL argument");
   MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_fused_epic_train_forward: dropout p=%f outside [0,1)", drop_p);
-  const int expect = 2 * (10 + 8 * nb_branch) + 1 + 8 * nb_fused_exec + 1 + 4;
+  const int expect = 2 * 10 + 8 * (nb_branch + nb_branch1) + 1 + 8 * nb_fused_exec + 1 + 4;
   MMB_REQUIRE(n_slots == expect, "mmb_fused_epic_train_forward: %d save slots given, the architecture has %d", n_slots,
               expect);
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
-              off_table, B, N, maskf, counts};
+              off_table, B, N, maskf, counts, nb_branch1};
   const SaveSlot* tab = reinterpret_cast<const SaveSlot*>(slots);
   const int grid = B < 4096 ? B : 4096;
-  if (variant == 0)
-    hipLaunchKernelGGL(fused_train_forward_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k,
-                       temb, temb_stride, tab, n_slots, drop_p, seed, offset0, head_c, head_d);
-  else
-    hipLaunchKernelGGL(fused_train_forward_kernel<DimsMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k,
-                       temb, temb_stride, tab, n_slots, drop_p, seed, offset0, head_c, head_d);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL(fused_train_forward_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k,
+                       temb, temb_stride, tab, n_slots, drop_p, seed, offset0, head_c, head_d); break;
+    case 1: hipLaunchKernelGGL(fused_train_forward_kernel<DimsMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k,
+                       temb, temb_stride, tab, n_slots, drop_p, seed, offset0, head_c, head_d); break;
+    case 2: hipLaunchKernelGGL(fused_train_forward_kernel<DimsWide>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k,
+                       temb, temb_stride, tab, n_slots, drop_p, seed, offset0, head_c, head_d); break;
+    default: hipLaunchKernelGGL(fused_train_forward_kernel<DimsNarrow>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k,
+                       temb, temb_stride, tab, n_slots, drop_p, seed, offset0, head_c, head_d); break;
+  }
   return check_launch("mmb_fused_epic_train_forward");
 }
 
@@ -848,17 +858,21 @@ extern "C" int mmb_fused_uni_forward(int variant, int B, int N, const float* pac
                                      float* head_d, void* stream) {
   int rc = check_fused("mmb_fused_uni_forward", B, N, packed, desc, maskf, counts);
   if (rc) return rc;
-  MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_uni_forward: unknown variant %d", variant);
+  MMB_REQUIRE(variant >= 0 && variant < N_UNI_VARIANTS, "mmb_fused_uni_forward: unknown variant %d", variant);
   MMB_REQUIRE(k && temb && head_d, "mmb_fused_uni_forward: NULL state");
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), num_blocks, 0, use_skip, 0, 0, off_table, B, N,
               maskf, counts};
   const int grid = B < 4096 ? B : 4096;
-  if (variant == 0)
-    hipLaunchKernelGGL(fused_uni_forward_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k, temb,
-                       temb_stride, head_d);
-  else
-    hipLaunchKernelGGL(fused_uni_forward_kernel<UniMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k, temb,
-                       temb_stride, head_d);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL(fused_uni_forward_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k, temb,
+                       temb_stride, head_d); break;
+    case 1: hipLaunchKernelGGL(fused_uni_forward_kernel<UniMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k, temb,
+                       temb_stride, head_d); break;
+    case 2: hipLaunchKernelGGL(fused_uni_forward_kernel<UniH64>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k, temb,
+                       temb_stride, head_d); break;
+    default: hipLaunchKernelGGL(fused_uni_forward_kernel<UniH32>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k, temb,
+                       temb_stride, head_d); break;
+  }
   return check_launch("mmb_fused_uni_forward");
 }
 
@@ -869,7 +883,7 @@ extern "C" int mmb_fused_uni_train_forward(int variant, int B, int N, const floa
                                            uint64_t seed, uint64_t offset0, float* head_d, void* stream) {
   int rc = check_fused("mmb_fused_uni_train_forward", B, N, packed, desc, maskf, counts);
   if (rc) return rc;
-  MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_uni_train_forward: unknown variant %d", variant);
+  MMB_REQUIRE(variant >= 0 && variant < N_UNI_VARIANTS, "mmb_fused_uni_train_forward: unknown variant %d", variant);
   MMB_REQUIRE(k && temb && head_d && slots, "mmb_fused_uni_train_forward: NULL argument");
   MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_fused_uni_train_forward: dropout p=%f outside [0,1)", drop_p);
   const int expect = 9 + 8 * num_blocks;
@@ -879,12 +893,16 @@ extern "C" int mmb_fused_uni_train_forward(int variant, int B, int N, const floa
               maskf, counts};
   const SaveSlot* tab = reinterpret_cast<const SaveSlot*>(slots);
   const int grid = B < 4096 ? B : 4096;
-  if (variant == 0)
-    hipLaunchKernelGGL(fused_uni_train_forward_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k,
-                       temb, temb_stride, tab, n_slots, drop_p, seed, offset0, head_d);
-  else
-    hipLaunchKernelGGL(fused_uni_train_forward_kernel<UniMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k,
-                       temb, temb_stride, tab, n_slots, drop_p, seed, offset0, head_d);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL(fused_uni_train_forward_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k,
+                       temb, temb_stride, tab, n_slots, drop_p, seed, offset0, head_d); break;
+    case 1: hipLaunchKernelGGL(fused_uni_train_forward_kernel<UniMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k,
+                       temb, temb_stride, tab, n_slots, drop_p, seed, offset0, head_d); break;
+    case 2: hipLaunchKernelGGL(fused_uni_train_forward_kernel<UniH64>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k,
+                       temb, temb_stride, tab, n_slots, drop_p, seed, offset0, head_d); break;
+    default: hipLaunchKernelGGL(fused_uni_train_forward_kernel<UniH32>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k,
+                       temb, temb_stride, tab, n_slots, drop_p, seed, offset0, head_d); break;
+  }
   return check_launch("mmb_fused_uni_train_forward");
 }
 
@@ -896,7 +914,7 @@ extern "C" int mmb_fused_uni_generate(int variant, int B, int N, const float* pa
                                       uint64_t offset, void* stream) {
   int rc = check_fused("mmb_fused_uni_generate", B, N, packed, desc, maskf, counts);
   if (rc) return rc;
-  MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_uni_generate: unknown variant %d", variant);
+  MMB_REQUIRE(variant >= 0 && variant < N_UNI_VARIANTS, "mmb_fused_uni_generate: unknown variant %d", variant);
   MMB_REQUIRE(k && times && temb_steps && steps > 0, "mmb_fused_uni_generate: NULL state / steps");
   MMB_REQUIRE(thermo_kind >= 0 && thermo_kind <= 4, "mmb_fused_uni_generate: bad thermostat");
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), num_blocks, 0, use_skip, 0, 0, off_table, B, N,
@@ -904,10 +922,12 @@ extern "C" int mmb_fused_uni_generate(int variant, int B, int N, const float* pa
   GenArgs Gn{steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, (float)(-(double)8 * (double)gamma), delta_n,
              seed, offset, 0, 0.0f, nullptr};
   const int grid = B < 4096 ? B : 4096;
-  if (variant == 0)
-    hipLaunchKernelGGL(fused_uni_generate_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k);
-  else
-    hipLaunchKernelGGL(fused_uni_generate_kernel<UniMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL(fused_uni_generate_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k); break;
+    case 1: hipLaunchKernelGGL(fused_uni_generate_kernel<UniMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k); break;
+    case 2: hipLaunchKernelGGL(fused_uni_generate_kernel<UniH64>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k); break;
+    default: hipLaunchKernelGGL(fused_uni_generate_kernel<UniH32>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k); break;
+  }
   return check_launch("mmb_fused_uni_generate");
 }
 
@@ -922,7 +942,7 @@ extern "C" int mmb_debug_fused_prof(unsigned long long* out16, int reset) {
 #endif
 
 extern "C" int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, const int32_t* desc,
-                                       int nb_branch, int nb_fused_exec, int use_skip, int off_cw, int off_cb,
+                                       int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip, int off_cw, int off_cb,
                                        int off_table, const float* maskf, const int32_t* counts, float* x, int64_t* k,
                                        int steps, const float* times, const float* temb_steps,
                                        const float* ctab_steps, int n_ctab, float dt,
@@ -930,17 +950,19 @@ extern "C" int mmb_fused_epic_generate(int variant, int B, int N, const float* p
                                        uint64_t offset, int em, float em_sigma, const float* delta_w, void* stream) {
   int rc = check_fused("mmb_fused_epic_generate", B, N, packed, desc, maskf, counts);
   if (rc) return rc;
-  MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_epic_generate: unknown variant %d", variant);
+  MMB_REQUIRE(variant >= 0 && variant < N_MULTI_VARIANTS, "mmb_fused_epic_generate: unknown variant %d", variant);
   MMB_REQUIRE(x && k && times && temb_steps && steps > 0, "mmb_fused_epic_generate: NULL state / steps");
   MMB_REQUIRE(thermo_kind >= 0 && thermo_kind <= 4, "mmb_fused_epic_generate: bad thermostat");
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
-              off_table, B, N, maskf, counts};
+              off_table, B, N, maskf, counts, nb_branch1};
   GenArgs Gn{steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, (float)(-(double)8 * (double)gamma), delta_n, seed, offset,
              em, em_sigma, delta_w};
   const int grid = B < 4096 ? B : 4096;
-  if (variant == 0)
-    hipLaunchKernelGGL(fused_generate_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k);
-  else
-    hipLaunchKernelGGL(fused_generate_kernel<DimsMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL(fused_generate_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k); break;
+    case 1: hipLaunchKernelGGL(fused_generate_kernel<DimsMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k); break;
+    case 2: hipLaunchKernelGGL(fused_generate_kernel<DimsWide>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k); break;
+    default: hipLaunchKernelGGL(fused_generate_kernel<DimsNarrow>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k); break;
+  }
   return check_launch("mmb_fused_epic_generate");
 }

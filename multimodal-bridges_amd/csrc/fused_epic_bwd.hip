@@ -34,7 +34,7 @@ struct alignas(16) LdsB {
 struct BwdArgs {
   const float* P;          // packed backward parameters
   const BDesc* D;
-  int nb_branch, nb_fused_exec, use_skip;
+  int nb_branch, nb_fused_exec, use_skip;      // nb_branch: continuous branch; nb_branch1 (below): discrete branch
   int B, N;
   const float* maskf;
   const int32_t* counts;
@@ -42,6 +42,7 @@ struct BwdArgs {
   int n_slots;
   float drop_p;
   uint64_t seed, offset0;
+  int nb_branch1;
 };
 
 __device__ __forceinline__ float gelu_grad(float z) {
@@ -269,9 +270,9 @@ fused_train_backward_kernel(BwdArgs A) {
   __shared__ float4 S[DM::HFT * 4 * FE_THREADS];
   constexpr int HBT = DM::HBT, HFT = DM::HFT, HB = DM::HB, GB = DM::GB, GF = DM::GF, ET = DM::ET;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-  const int nb = A.nb_branch, nbf = A.nb_fused_exec;
+  const int nb0 = A.nb_branch, nb1 = A.nb_branch1, nbf = A.nb_fused_exec;
   const bool use_skip = A.use_skip != 0;
-  const int base_f = 2 * (5 + 4 * nb), base_h = base_f + 4 * nbf + 1;
+  const int base_f = 2 * 5 + 4 * (nb0 + nb1), base_h = base_f + 4 * nbf + 1;
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
     __syncthreads();
     const int p = 32 * wave + (lane & 31);
@@ -338,7 +339,7 @@ fused_train_backward_kernel(BwdArgs A) {
       if (tid < GF) LB.dgskip[tid] = 0.0f;
       __syncthreads();
       for (int i = nbf - 1; i >= 0; --i) {
-        const uint64_t j = (uint64_t)(2 * nb + i);
+        const uint64_t j = (uint64_t)(nb0 + nb1 + i);
         EpicB<HFT, ET, GF>::layer_bwd(dx, A.D + base_f + 4 * i, A.P, use_skip, LB, S, sl, m, tid, A.drop_p, A.seed,
                                       A.offset0 + 2 * j + 1, A.offset0 + 2 * j + 2);
       }
@@ -357,7 +358,8 @@ fused_train_backward_kernel(BwdArgs A) {
     // ---- the two branch encoders
     ffor<2>([&](auto bc) {
       constexpr int br = decltype(bc)::v;
-      const int base_b = br * (5 + 4 * nb);
+      const int nb = br == 0 ? nb0 : nb1;
+      const int base_b = br * (5 + 4 * nb0);
       f32x16 dx[HBT];
       {
         f32x16 dout[HBT];
@@ -374,7 +376,7 @@ fused_train_backward_kernel(BwdArgs A) {
       if (tid < GB) LB.dgskip[tid] = 0.0f;
       __syncthreads();
       for (int i = nb - 1; i >= 0; --i) {
-        const uint64_t j = (uint64_t)(br * nb + i);
+        const uint64_t j = (uint64_t)(br * nb0 + i);
         EpicB<HBT, ET, GB>::layer_bwd(dx, A.D + base_b + 4 + 4 * i, A.P, use_skip, LB, S, sl, m, tid, A.drop_p, A.seed,
                                       A.offset0 + 2 * j + 1, A.offset0 + 2 * j + 2);
       }
@@ -448,7 +450,7 @@ extern "C" int mmb_fused_uni_train_backward(int variant, int B, int N, const flo
                                             uint64_t offset0, void* stream) {
   MMB_REQUIRE(B > 0 && N > 0 && N <= 128, "mmb_fused_uni_train_backward: needs 0 < N <= 128 (got B=%d N=%d)", B, N);
   MMB_REQUIRE(packed_bwd && desc_bwd && maskf && counts && slots, "mmb_fused_uni_train_backward: NULL argument");
-  MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_uni_train_backward: unknown variant %d", variant);
+  MMB_REQUIRE(variant >= 0 && variant < N_UNI_VARIANTS, "mmb_fused_uni_train_backward: unknown variant %d", variant);
   MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_fused_uni_train_backward: dropout p=%f outside [0,1)", drop_p);
   const int expect = 1 + 2 + num_blocks * 9 + 9;
   MMB_REQUIRE(n_slots == expect, "mmb_fused_uni_train_backward: %d slots given, the architecture has %d", n_slots,
@@ -456,31 +458,36 @@ extern "C" int mmb_fused_uni_train_backward(int variant, int B, int N, const flo
   BwdArgs A{packed_bwd, reinterpret_cast<const BDesc*>(desc_bwd), num_blocks, 0, use_skip, B, N, maskf,
             counts, reinterpret_cast<const SaveSlot*>(slots), n_slots, drop_p, seed, offset0};
   const int grid = B < 4096 ? B : 4096;
-  if (variant == 0)
-    hipLaunchKernelGGL(fused_uni_train_backward_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A);
-  else
-    hipLaunchKernelGGL(fused_uni_train_backward_kernel<UniMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL(fused_uni_train_backward_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A); break;
+    case 1: hipLaunchKernelGGL(fused_uni_train_backward_kernel<UniMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A); break;
+    case 2: hipLaunchKernelGGL(fused_uni_train_backward_kernel<UniH64>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A); break;
+    default: hipLaunchKernelGGL(fused_uni_train_backward_kernel<UniH32>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A); break;
+  }
   return check_launch("mmb_fused_uni_train_backward");
 }
 
 extern "C" int mmb_fused_epic_train_backward(int variant, int B, int N, const float* packed_bwd, const int32_t* desc_bwd,
-                                             int nb_branch, int nb_fused_exec, int use_skip, const float* maskf,
+                                             int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip,
+                                             const float* maskf,
                                              const int32_t* counts, const void* slots, int n_slots, float drop_p,
                                              uint64_t seed, uint64_t offset0, void* stream) {
   MMB_REQUIRE(B > 0 && N > 0 && N <= 128, "mmb_fused_epic_train_backward: needs 0 < N <= 128 (got B=%d N=%d)", B, N);
   MMB_REQUIRE(packed_bwd && desc_bwd && maskf && counts && slots, "mmb_fused_epic_train_backward: NULL argument");
-  MMB_REQUIRE(variant == 0 || variant == 1, "mmb_fused_epic_train_backward: unknown variant %d", variant);
+  MMB_REQUIRE(variant >= 0 && variant < N_MULTI_VARIANTS, "mmb_fused_epic_train_backward: unknown variant %d", variant);
   MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_fused_epic_train_backward: dropout p=%f outside [0,1)", drop_p);
   const int per_layer = 9;
-  const int expect = 4 + 8 + (1 + nb_fused_exec * per_layer) + 2 * (1 + nb_branch * per_layer + 9) + 1;
+  const int expect = 4 + 8 + (1 + nb_fused_exec * per_layer) + 2 * (1 + 9) + (nb_branch + nb_branch1) * per_layer + 1;
   MMB_REQUIRE(n_slots == expect, "mmb_fused_epic_train_backward: %d slots given, the architecture has %d", n_slots,
               expect);
   BwdArgs A{packed_bwd, reinterpret_cast<const BDesc*>(desc_bwd), nb_branch, nb_fused_exec, use_skip, B, N, maskf,
-            counts, reinterpret_cast<const SaveSlot*>(slots), n_slots, drop_p, seed, offset0};
+            counts, reinterpret_cast<const SaveSlot*>(slots), n_slots, drop_p, seed, offset0, nb_branch1};
   const int grid = B < 4096 ? B : 4096;
-  if (variant == 0)
-    hipLaunchKernelGGL(fused_train_backward_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A);
-  else
-    hipLaunchKernelGGL(fused_train_backward_kernel<DimsMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL(fused_train_backward_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A); break;
+    case 1: hipLaunchKernelGGL(fused_train_backward_kernel<DimsMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A); break;
+    case 2: hipLaunchKernelGGL(fused_train_backward_kernel<DimsWide>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A); break;
+    default: hipLaunchKernelGGL(fused_train_backward_kernel<DimsNarrow>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A); break;
+  }
   return check_launch("mmb_fused_epic_train_backward");
 }

@@ -58,13 +58,13 @@ SIGNATURES = {
     "mmb_jet_sum": [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int, c_stream],
     "mmb_pool_bwd": [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, c_i32p, c_f32p, C.c_int64, C.c_int,
                      c_stream],
-    "mmb_fused_epic_forward": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+    "mmb_fused_epic_forward": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, c_f32p, c_i32p, c_f32p, c_i64p, c_f32p, C.c_int64, C.c_int, c_f32p, c_f32p,
                                c_stream],
-    "mmb_fused_epic_train_forward": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int,
+    "mmb_fused_epic_train_forward": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, c_f32p, c_i32p, c_f32p, c_i64p, c_f32p, C.c_int64, C.c_void_p,
                                      C.c_int, C.c_float, C.c_uint64, C.c_uint64, c_f32p, c_f32p, c_stream],
-    "mmb_fused_epic_train_backward": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, c_f32p,
+    "mmb_fused_epic_train_backward": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
                                       c_i32p, C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint64, c_stream],
     "mmb_grad_weight_smallk": [C.c_int, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p,
                                c_stream],
@@ -77,7 +77,7 @@ SIGNATURES = {
                                     c_f32p, c_stream],
     "mmb_fused_uni_train_backward": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, c_f32p, c_i32p,
                                      C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint64, c_stream],
-    "mmb_fused_epic_generate": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int,
+    "mmb_fused_epic_generate": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, c_f32p, c_i32p, c_f32p, c_i64p, C.c_int, c_f32p, c_f32p, c_f32p,
                                 C.c_int, C.c_float,
                                 C.c_int, C.c_float, c_f32p, C.c_uint64, C.c_uint64, C.c_int, C.c_float, c_f32p,

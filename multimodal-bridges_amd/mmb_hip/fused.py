@@ -20,15 +20,19 @@ import torch
 from . import call
 from .ops import f32, i32, i64, stream, _fl
 
-VARIANTS = {  # (Et, Ec, Ed, Hb, Gb) -> variant id (fused_epic.hip: DimsS3 / DimsMid)
+VARIANTS = {  # (Et, Ec, Ed, Hb, Gb) -> variant id (csrc/fused_common.h: DimsS3 / DimsMid / DimsWide / DimsNarrow)
     (32, 16, 16, 64, 16): 0,
     (16, 8, 8, 32, 8): 1,
+    (64, 32, 32, 64, 32): 2,
+    (32, 16, 16, 32, 16): 3,
 }
 
 
-UNI_VARIANTS = {  # (Et, Ed, H, G) -> variant id (fused_epic.hip: UniS2 / UniMid)
+UNI_VARIANTS = {  # (Et, Ed, H, G) -> variant id (csrc/fused_common.h: UniS2 / UniMid / UniH64 / UniH32)
     (128, 128, 128, 16): 0,
     (16, 16, 32, 8): 1,
+    (64, 64, 64, 16): 2,
+    (32, 32, 32, 16): 3,
 }
 MAX_TIME_LAYERS = 64
 
@@ -63,8 +67,6 @@ def eligible(model):
     H0, H1, H2, half = enc.dims
     hl, hg = e.dim_hidden_local, e.dim_hidden_glob
     if H0 != H1 or H2 != H0 + H1 or hg[0] != hg[1] or hg[2] != hg[0] + hg[1]:
-        return None
-    if e.num_blocks[0] != e.num_blocks[1]:
         return None
     if e.dim_emb_context_continuous or e.dim_emb_context_discrete:
         return None
@@ -545,6 +547,7 @@ def _pack_multi(model, variant, src):
     off_table = pk.add(src.tensor(emb.discrete_embedding.table, emb.discrete_embedding))
     main, xs, desc = pk.finish()
     return {"kind": "multi", "main": main, "xs": xs, "time_lins": pk.time_lins, "desc": desc, "variant": variant, "nb_branch": enc.continuous_encoder.num_blocks,
+            "nb_branch1": enc.discrete_encoder.num_blocks,
             "nb_fused_exec": fe.num_blocks, "use_skip": int(bool(cfg.encoder.skip_connection)),
             "off_cw": off_cw, "off_cb": off_cb, "off_table": off_table, "time_parts": pk.time_parts,
             # a generation forward evaluates ONE head (the last four particle layers are head_c.0/.2, head_d.0/.2)
@@ -583,8 +586,8 @@ def forward(pack, mi, x, k, temb, which, temb_stride=None):
     hd = torch.empty(B, N, 8, dtype=torch.float32, device=dev) if which != 0 else None
     stride = temb.stride(0) if temb_stride is None else temb_stride
     call("mmb_fused_epic_forward", pack["variant"], B, N, f32(pack["packed"]), i32(pack["desc"]), pack["nb_branch"],
-         pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"], pack["off_table"], f32(mi.maskf),
-         i32(mi.counts), f32(x, "x"), i64(k, "k"), f32(temb, "temb"), stride, which, f32(hc), f32(hd), stream())
+         pack["nb_branch1"], pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"], pack["off_table"],
+         f32(mi.maskf), i32(mi.counts), f32(x, "x"), i64(k, "k"), f32(temb, "temb"), stride, which, f32(hc), f32(hd), stream())
     return hc, hd
 
 
@@ -596,8 +599,8 @@ def train_forward(pack, mi, x, k, temb, slots, n_slots, drop_p, seed, offset0, h
     hc = torch.empty(B * N, 3, dtype=torch.float32, device=dev) if hc is None else hc
     hd = torch.empty(B * N, 8, dtype=torch.float32, device=dev) if hd is None else hd
     call("mmb_fused_epic_train_forward", pack["variant"], B, N, f32(pack["packed"]), i32(pack["desc"]),
-         pack["nb_branch"], pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"], pack["off_table"],
-         f32(mi.maskf), i32(mi.counts), f32(x, "x"), i64(k, "k"), f32(temb, "temb"), temb.stride(0),
+         pack["nb_branch"], pack["nb_branch1"], pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"],
+         pack["off_table"], f32(mi.maskf), i32(mi.counts), f32(x, "x"), i64(k, "k"), f32(temb, "temb"), temb.stride(0),
          C.c_void_p(slots.data_ptr()), n_slots, _fl(drop_p), seed, offset0, f32(hc), f32(hd), stream())
     return hc, hd
 
@@ -620,7 +623,8 @@ def train_backward(pack, pbwd, mi, slots, n_slots, drop_p, seed, offset0):
              _fl(drop_p), seed, offset0, stream())
         return
     call("mmb_fused_epic_train_backward", pack["variant"], mi.B, mi.N, f32(pbwd), i32(pack["desc_bwd"]), pack["nb_branch"],
-         pack["nb_fused_exec"], pack["use_skip"], f32(mi.maskf), i32(mi.counts), C.c_void_p(slots.data_ptr()), n_slots,
+         pack["nb_branch1"], pack["nb_fused_exec"], pack["use_skip"], f32(mi.maskf), i32(mi.counts),
+         C.c_void_p(slots.data_ptr()), n_slots,
          _fl(drop_p), seed, offset0, stream())
 
 
@@ -631,8 +635,8 @@ def generate(pack, mi, x, k, times, temb_steps, dt, thermo_kind, gamma, delta_n=
     B, N = mi.B, mi.N
     n_ctab = 0 if ctab is None else ctab.shape[1]
     call("mmb_fused_epic_generate", pack["variant"], B, N, f32(pack["packed"]), i32(pack["desc"]), pack["nb_branch"],
-         pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"], pack["off_table"], f32(mi.maskf),
-         i32(mi.counts), f32(x, "x"), i64(k, "k"), times.numel(), f32(times, "times"), f32(temb_steps, "temb_steps"),
+         pack["nb_branch1"], pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"], pack["off_table"],
+         f32(mi.maskf), i32(mi.counts), f32(x, "x"), i64(k, "k"), times.numel(), f32(times, "times"), f32(temb_steps, "temb_steps"),
          f32(ctab, "ctab"), n_ctab, _fl(dt), thermo_kind, _fl(gamma), f32(delta_n, "delta_n"), seed, offset,
          0 if em_sigma is None else 1, _fl(0.0 if em_sigma is None else em_sigma), f32(delta_w, "delta_w"), stream())
 

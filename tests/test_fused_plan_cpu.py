@@ -19,7 +19,8 @@ def _model(golden, name, blocks, skip):
     return MultiModalBridgeMatching(ExperimentConfigs(cfg))
 
 
-@pytest.mark.parametrize("blocks,skip", [([1, 1, 2], False), ([3, 3, 1], True), ([2, 2, 4], True)])
+@pytest.mark.parametrize("blocks,skip", [([1, 1, 2], False), ([3, 3, 1], True), ([2, 2, 4], True), ([1, 3, 2], True),
+                                         ([2, 1, 3], False)])
 def test_multi_plan_counts(golden, blocks, skip):
     from encoders import fused_train as ft
     model = _model(golden, "mm_mid", blocks, skip)
@@ -29,16 +30,18 @@ def test_multi_plan_counts(golden, blocks, skip):
     pl = ft._Plan(B, N, torch.device("cpu"), [], 0.1, 0)
     temb, cont, disc = torch.empty(B, e.dim_emb_time), torch.empty(M, e.dim_emb_continuous), torch.empty(M, e.dim_emb_discrete)
     ft._plan_forward(model, pl, temb, cont, disc, torch.empty(M, 3), torch.empty(M, 8))
-    nb, nbf = model.encoder.continuous_encoder.num_blocks, model.encoder.fused_encoder.num_blocks
+    nb0, nb1 = model.encoder.continuous_encoder.num_blocks, model.encoder.discrete_encoder.num_blocks
+    nbf = model.encoder.fused_encoder.num_blocks
+    assert (nb0, nb1) == (blocks[0], blocks[1])                    # the two branch depths may differ
     assert nbf == blocks[2] - 1                                   # K2: one constructed layer never runs
-    assert len(pl.slots) == 2 * (10 + 8 * nb) + 1 + 8 * nbf + 1 + 4
+    assert len(pl.slots) == 2 * 10 + 8 * (nb0 + nb1) + 1 + 8 * nbf + 1 + 4
     for ptr, ld, n in pl.slots:
         assert ptr % 16 == 0 and ld > 0 and n >= ld
     # dropout offsets are handed out in execution order, two per executed layer
     offs = [en[12] for en in pl.tape if en[0] == "linear" and en[11] > 0.0]
-    assert offs == list(range(1, 2 * (2 * nb + nbf) + 1))
+    assert offs == list(range(1, 2 * (nb0 + nb1 + nbf) + 1))
     bp = ft._plan_backward(pl, (torch.empty(M, 4), torch.empty(M, 8)), cont.shape[1])
-    assert bp["n"] == 4 + 8 + (1 + 9 * nbf) + 2 * (1 + 9 * nb + 9) + 1
+    assert bp["n"] == 4 + 8 + (1 + 9 * nbf) + 2 * (1 + 9) + 9 * (nb0 + nb1) + 1
     # one weight-gradient job per executed weight-normed Linear
     n_lin = sum(1 for en in pl.tape if en[0] == "linear")
     assert len(bp["jobs"]) == n_lin

@@ -8,6 +8,8 @@
 // thread owns one query and streams the keys with an online softmax (LDS reads are wave-wide broadcasts).
 // A query with no valid key gets zeros, as torch's need_weights=False path does (safe softmax).
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace mmb {
 
@@ -202,6 +204,387 @@ attn_bwd_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int
   }
 }
 
+// ---- the same two ops on the matrix cores (fp32 MFMA, v_mfma_f32_32x32x2_f32) ---------------------------------
+// One wave owns a tile of 32 queries (lane & 31 = query) and walks the valid keys 32 at a time.  Everything is kept
+// TRANSPOSED so that no tile ever changes layout between two products:
+//   S^T (keys x queries) = K Q^T      A = K rows from LDS (lane = key, its half of the head dims), B = Q^T registers
+//   softmax over keys    = over the 16 registers of the lane + one exchange with lane ^ 32
+//   O^T (dims x queries) += V^T P^T   B = the registers of P^T AS THEY ARE: step r contracts the two keys that
+//                                     register r holds in the two lane halves, A = those two rows of V (lane = dim)
+// The backward uses the same two shapes five times: phase A (wave = query tile) S^T, dP^T = V dO^T, dQ^T += K^T dS^T;
+// phase B (wave = key tile, lane & 31 = key) S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS.
+// LDS rows have a pitch of DH + 4 floats (conflict-free 16-byte row reads); rows past the last valid key / query
+// and columns past the head width are zeros.  For DH = 16 the dim-tile of the second product is half empty (lanes
+// 16..31 read the next row: finite junk that only reaches output rows nobody stores).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+#define MMB_MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// the valid keys of a jet of N <= 256 particles: every lane fetches its (up to four) mask entries BEFORE the first
+// ballot, so the scan costs one memory latency instead of one per 64 particles
+__device__ inline void compact_keys256(const float* __restrict__ maskf, int N, int valid_is_zero, int* idx,
+                                       int* pos, int* nk_sh) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    float mv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) mv[c] = c * 64 + lane < N ? maskf[c * 64 + lane] : 0.0f;
+    int base = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool ok = c * 64 + lane < N && ((mv[c] == 0.0f) == (valid_is_zero != 0));
+      const unsigned long long bal = __ballot(ok);
+      const int p = base + __popcll(bal & ((1ull << lane) - 1ull));
+      if (ok) idx[p] = c * 64 + lane;
+      if (c * 64 + lane < N) pos[c * 64 + lane] = ok ? p : -1;
+      base += __popcll(bal);
+    }
+    if (lane == 0) *nk_sh = base;
+  }
+}
+
+// K and V rows of the jet's valid keys, compacted, into LDS (pitch DH + 4; rows in [nk, pad32(nk)) and columns >= dh
+// are zeros); returns nk.  VEC: every thread fetches its 16-byte pieces of ALL N rows while wave 0 scans the mask,
+// so the whole prologue costs one memory latency; the pieces of keys that take no part are dropped.
+template <int DH, bool VEC>
+__device__ inline int stage_keys(const float* __restrict__ maskf, int N, int valid_is_zero, const float* __restrict__ k0,
+                                 const float* __restrict__ v0, int64_t ld, int dh, int* idx, int* pos, int* nk_sh,
+                                 float* Ks, float* Vs) {
+  constexpr int P = DH + 4;
+  if constexpr (VEC) {
+    constexpr int C = DH / 4, U = C / 2;              // blockDim >= 2 N threads: U pieces per thread cover N * C
+    float4 a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = threadIdx.x + u * blockDim.x, j = i / C, c = i - j * C;
+      a[u] = b[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (j < N && 4 * c < dh) {
+        a[u] = *reinterpret_cast<const float4*>(k0 + (int64_t)j * ld + 4 * c);
+        b[u] = *reinterpret_cast<const float4*>(v0 + (int64_t)j * ld + 4 * c);
+      }
+    }
+    compact_keys256(maskf, N, valid_is_zero, idx, pos, nk_sh);
+    __syncthreads();
+    const int nk = *nk_sh, nkp = (nk + 31) & ~31;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = threadIdx.x + u * blockDim.x, j = i / C, c = i - j * C;
+      if (j < N) {
+        const int pj = pos[j];
+        if (pj >= 0) {
+          *reinterpret_cast<float4*>(Ks + pj * P + 4 * c) = a[u];
+          *reinterpret_cast<float4*>(Vs + pj * P + 4 * c) = b[u];
+        }
+      }
+    }
+    for (int i = threadIdx.x; i < (nkp - nk) * C; i += blockDim.x) {
+      const int j = nk + i / C, c = i % C;
+      *reinterpret_cast<float4*>(Ks + j * P + 4 * c) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      *reinterpret_cast<float4*>(Vs + j * P + 4 * c) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    __syncthreads();
+    return nk;
+  } else {
+    compact_keys256(maskf, N, valid_is_zero, idx, pos, nk_sh);
+    __syncthreads();
+    const int nk = *nk_sh, nkp = (nk + 31) & ~31;
+    for (int i = threadIdx.x; i < nkp * DH; i += blockDim.x) {
+      const int j = i / DH, d = i - j * DH;
+      float a = 0.0f, b = 0.0f;
+      if (j < nk && d < dh) {
+        const int64_t row = idx[j];
+        a = k0[row * ld + d];
+        b = v0[row * ld + d];
+      }
+      Ks[j * P + d] = a;
+      Vs[j * P + d] = b;
+    }
+    __syncthreads();
+    return nk;
+  }
+}
+
+// the lane's half of one row (HD consecutive floats from p, those past `lim` are zeros), times scale
+template <int HD, bool VEC>
+__device__ __forceinline__ void load_half(float (&r)[HD], const float* __restrict__ p, bool ok, int lim, float scale) {
+  if constexpr (VEC) {
+#pragma unroll
+    for (int i = 0; i < HD; i += 4) {
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (ok && i < lim) v = *reinterpret_cast<const float4*>(p + i);
+      r[i] = v.x * scale; r[i + 1] = v.y * scale; r[i + 2] = v.z * scale; r[i + 3] = v.w * scale;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < HD; ++i) r[i] = (ok && i < lim) ? p[i] * scale : 0.0f;
+  }
+}
+
+// a transposed result tile (lane & 31 = row of the output matrix, registers = head dims) to global memory
+template <int DT, bool VEC>
+__device__ __forceinline__ void store_tile_t(float* __restrict__ o, const f32x16 (&acc)[DT], int par, int dh, float mul) {
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = t * 32 + 8 * g + 4 * par;
+        if (d < dh)
+          *reinterpret_cast<float4*>(o + d) = make_float4(acc[t][4 * g] * mul, acc[t][4 * g + 1] * mul,
+                                                          acc[t][4 * g + 2] * mul, acc[t][4 * g + 3] * mul);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = t * 32 + crow(r, par);
+        if (d < dh) o[d] = acc[t][r] * mul;
+      }
+    }
+  }
+}
+
+template <int DH, bool VEC>
+__global__ void __launch_bounds__(512)
+attn_fwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int64_t ld,
+                     const float* __restrict__ maskf, int valid_is_zero, float scale, float* __restrict__ out,
+                     int64_t out_ld, float* __restrict__ lse) {
+  constexpr int P = DH + 4, HD = DH / 2, DT = (DH + 31) / 32;
+  extern __shared__ float sm[];
+  const int b = blockIdx.x / nh, h = blockIdx.x - b * nh;
+  const int NP = (N + 31) & ~31;
+  int* idx = reinterpret_cast<int*>(sm);
+  int* pos = idx + N;
+  int* nk_sh = pos + N;
+  float* Ks = sm + ((2 * N + 1 + 3) & ~3);
+  float* Vs = Ks + (size_t)NP * P;
+  const float* base = qkv + (int64_t)b * N * ld + h * dh;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, lane = threadIdx.x & 63, col = lane & 31,
+            par = lane >> 5;
+  float qr[HD];                                  // the first query tile's rows are fetched beside the keys
+  load_half<HD, VEC>(qr, base + (int64_t)(wave * 32 + col) * ld + par * HD, wave * 32 + col < N, dh - par * HD, scale * LOG2E);
+  const int nk = stage_keys<DH, VEC>(maskf + (int64_t)b * N, N, valid_is_zero, base + H, base + 2 * H, ld, dh, idx, pos,
+                                     nk_sh, Ks, Vs);
+  const int nkp = (nk + 31) & ~31;
+  for (int qt = wave * 32; qt < N; qt += nwaves * 32) {
+    const int q = qt + col;
+    if (qt != wave * 32)
+      load_half<HD, VEC>(qr, base + (int64_t)q * ld + par * HD, q < N, dh - par * HD, scale * LOG2E);
+    f32x16 acc[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float m = -INFINITY, l = 0.0f;              // (scores and m in units of log 2: qr carries scale * log2(e))
+    for (int kt = 0; kt < nkp; kt += 32) {
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+      const float* kr = Ks + (kt + col) * P + par * HD;
+#pragma unroll
+      for (int i = 0; i < HD; ++i) s = MMB_MFMA_F32(kr[i], qr[i], s);
+      float va[DT][16];                          // the V operands of the second product: in flight during the softmax
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) va[t][r] = Vs[(kt + crow(r, par)) * P + t * 32 + col];
+      if (kt + 32 > nk) {                        // only the last tile has keys to mask
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt + crow(r, par) >= nk) s[r] = -INFINITY;
+      }
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));             // key kt of this tile is valid: finite
+      const float mn = fmaxf(m, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      float ps = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = __builtin_amdgcn_exp2f(s[r] - mn);
+        ps += s[r];
+      }
+      ps += __shfl_xor(ps, 32);
+      l = fmaf(l, alpha, ps);
+      m = mn;
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t] = MMB_MFMA_F32(va[t][r], s[r], acc[t]);
+      }
+    }
+    if (q < N) {
+      store_tile_t<DT, VEC>(out + ((int64_t)b * N + q) * out_ld + h * dh, acc, par, dh, nk > 0 ? 1.0f / l : 0.0f);
+      if (lse && par == 0) lse[((int64_t)b * nh + h) * N + q] = nk > 0 ? (m + __log2f(l)) * LN2 : 0.0f;
+    }
+  }
+}
+
+template <int DH, bool VEC>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DH == 16 ? 4 : 3)))
+attn_bwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int64_t ld,
+                     const float* __restrict__ maskf, int valid_is_zero, float scale, const float* __restrict__ out,
+                     int64_t out_ld, const float* __restrict__ dout, int64_t dout_ld, const float* __restrict__ lse,
+                     float* __restrict__ dqkv, int64_t dld) {
+  constexpr int P = DH + 4, HD = DH / 2, DT = (DH + 31) / 32;
+  extern __shared__ float sm[];
+  const int b = blockIdx.x / nh, h = blockIdx.x - b * nh;
+  const int NP = (N + 31) & ~31;
+  int* idx = reinterpret_cast<int*>(sm);
+  int* pos = idx + N;
+  int* nk_sh = pos + N;
+  float* Ls = sm + ((2 * N + 1 + 3) & ~3);
+  float* Ds = Ls + NP;
+  float* A0 = Ds + NP;                         // K (phase A) / scale * Q (phase B)
+  float* A1 = A0 + (size_t)NP * P;             // V (phase A) / dO (phase B)
+  const float* base = qkv + (int64_t)b * N * ld + h * dh;
+  const float* obase = out + (int64_t)b * N * out_ld + h * dh;
+  const float* gbase = dout + (int64_t)b * N * dout_ld + h * dh;
+  float* dbase = dqkv + (int64_t)b * N * dld + h * dh;
+  const float* lrow = lse + ((int64_t)b * nh + h) * N;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, lane = threadIdx.x & 63, col = lane & 31,
+            par = lane >> 5;
+  // the block has one wave per query tile (host): the tile's rows of Q, dO, O and its L are fetched beside the keys,
+  // and stay in registers until phase B takes them over through LDS -- one memory latency for the whole kernel
+  const int q = wave * 32 + col;
+  float qr[HD], gr[HD];
+  float D = 0.0f;
+  {
+    float orow[HD];
+    load_half<HD, VEC>(qr, base + (int64_t)q * ld + par * HD, q < N, dh - par * HD, scale * LOG2E);
+    load_half<HD, VEC>(gr, gbase + (int64_t)q * dout_ld + par * HD, q < N, dh - par * HD, 1.0f);
+    load_half<HD, VEC>(orow, obase + (int64_t)q * out_ld + par * HD, q < N, dh - par * HD, 1.0f);
+    const float L0 = q < N ? lrow[q] * LOG2E : 0.0f;      // (units of log 2, as the scores)
+    if (par == 0) Ls[q] = L0;                  // (Ls, Ds are not touched by stage_keys)
+#pragma unroll
+    for (int i = 0; i < HD; ++i) D = fmaf(gr[i], orow[i], D);
+  }
+  const int nk = stage_keys<DH, VEC>(maskf + (int64_t)b * N, N, valid_is_zero, base + H, base + 2 * H, ld, dh, idx, pos,
+                                     nk_sh, A0, A1);
+  const int nkp = (nk + 31) & ~31;
+  // ---- phase A: D, dQ (wave = query tile)
+  {
+    D += __shfl_xor(D, 32);
+    const float L = Ls[q];
+    f32x16 dq[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[t][r] = 0.0f;
+    for (int kt = 0; kt < nkp; kt += 32) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.0f;
+      const float* kr = A0 + (kt + col) * P + par * HD;
+      const float* vr = A1 + (kt + col) * P + par * HD;
+#pragma unroll
+      for (int i = 0; i < HD; ++i) {
+        s = MMB_MFMA_F32(kr[i], qr[i], s);
+        dp = MMB_MFMA_F32(vr[i], gr[i], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = kt + crow(r, par) < nk ? __builtin_amdgcn_exp2f(s[r] - L) : 0.0f;
+        s[r] = p * (dp[r] - D);
+      }
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dq[t] = MMB_MFMA_F32(A0[(kt + crow(r, par)) * P + t * 32 + col], s[r], dq[t]);
+    }
+    if (par == 0) Ds[q] = D;
+    if (q < N) store_tile_t<DT, VEC>(dbase + (int64_t)q * dld, dq, par, dh, scale);
+  }
+  // ---- phase B: dK, dV (wave = key tile; its K, V rows move to registers, the LDS area is re-filled with Q, dO)
+  for (int kt0 = 0; kt0 < nkp; kt0 += nwaves * 32) {          // nkp is uniform over the block: so are the barriers
+    const int kt = kt0 + wave * 32;
+    const bool active = kt < nkp;
+    float kreg[HD], vreg[HD];
+#pragma unroll
+    for (int i = 0; i < HD; ++i) {
+      kreg[i] = active ? A0[(kt + col) * P + par * HD + i] : 0.0f;
+      vreg[i] = active ? A1[(kt + col) * P + par * HD + i] : 0.0f;
+    }
+    __syncthreads();
+    if (kt0 == 0) {                            // scale * Q and dO rows of this wave's tile: registers -> LDS
+#pragma unroll
+      for (int i = 0; i < HD; ++i) {
+        A0[q * P + par * HD + i] = qr[i];
+        A1[q * P + par * HD + i] = gr[i];
+      }
+    }
+    __syncthreads();
+    if (active) {
+      f32x16 dk[DT], dv[DT];
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[t][r] = dv[t][r] = 0.0f;
+      for (int qt = 0; qt < NP; qt += 32) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.0f;
+        const float* qrow = A0 + (qt + col) * P + par * HD;
+        const float* grow = A1 + (qt + col) * P + par * HD;
+#pragma unroll
+        for (int i = 0; i < HD; ++i) {
+          s = MMB_MFMA_F32(qrow[i], kreg[i], s);
+          dp = MMB_MFMA_F32(grow[i], vreg[i], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qq = qt + crow(r, par);
+          const float p = qq < N ? __builtin_amdgcn_exp2f(s[r] - Ls[qq]) : 0.0f;
+          dp[r] = p * (dp[r] - Ds[qq]);
+          s[r] = p;
+        }
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = (qt + crow(r, par)) * P + t * 32 + col;
+            dv[t] = MMB_MFMA_F32(A1[o], s[r], dv[t]);
+            dk[t] = MMB_MFMA_F32(A0[o], dp[r], dk[t]);
+          }
+      }
+      const int key = kt + col;
+      if (key < nk) {
+        float* drow = dbase + (int64_t)idx[key] * dld;
+        store_tile_t<DT, VEC>(drow + H, dk, par, dh, LN2);         // Q in LDS carries scale * log2(e)
+        store_tile_t<DT, VEC>(drow + 2 * H, dv, par, dh, 1.0f);
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < N * dh; i += blockDim.x) {     // keys outside the valid set: zero gradient
+    const int n = i / dh, d = i - n * dh;
+    const bool ok = ((maskf[(int64_t)b * N + n] == 0.0f) == (valid_is_zero != 0));
+    if (!ok) {
+      dbase[(int64_t)n * dld + H + d] = 0.0f;
+      dbase[(int64_t)n * dld + 2 * H + d] = 0.0f;
+    }
+  }
+}
+
+// LDS of the MFMA kernels: idx + nk, (L, D), two row arrays of pitch DH + 4, 32 floats of slack
+static size_t attn_mfma_lds_bytes(int N, int DH, bool bwd) {
+  const size_t NP = (N + 31) & ~31;
+  size_t fl = ((2 * N + 1 + 3) & ~3) + 2 * NP * (DH + 4) + 32;
+  if (bwd) fl += 2 * NP;
+  return fl * sizeof(float);
+}
+// the matrix-core kernels serve head widths <= 32 and jets of <= 256 particles that fit 64 KiB of LDS
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static bool attn_use_mfma(int N, int dh, bool bwd) {
+  if (dh > 32 || N > 256) return false;
+  const char* e = getenv("MMB_ATTN_PATH");
+  if (e && !strcmp(e, "valu")) return false;                // A/B switch for tests and profiles
+  return attn_mfma_lds_bytes(N, dh <= 16 ? 16 : 32, bwd) <= 64 * 1024;
+}
+
 // ---- LayerNorm over the last dim, one wave per row --------------------------------------------------------
 __global__ void __launch_bounds__(256)
 layernorm_fwd_kernel(int64_t M, int D, const float* __restrict__ x, int64_t x_ld, const float* __restrict__ gamma,
@@ -339,12 +722,24 @@ extern "C" int mmb_attention_fwd(int B, int N, int H, int nheads, const float* q
                                  void* stream) {
   MMB_REQUIRE(qkv && maskf && out, "mmb_attention_fwd: NULL argument");
   const int dh = nheads > 0 ? H / nheads : 0, dhp = pad_dh(dh);
-  const size_t lds = attn_lds_bytes(N, dhp, false);
+  const bool mfma = N > 0 && dh > 0 && attn_use_mfma(N, dh, false);
+  const size_t lds = mfma ? attn_mfma_lds_bytes(N, dh <= 16 ? 16 : 32, false) : attn_lds_bytes(N, dhp, false);
   if (int rc = attn_check("mmb_attention_fwd", B, N, H, nheads, qkv_ld, lds)) return rc;
   MMB_REQUIRE(out_ld >= H, "mmb_attention_fwd: out row stride < H");
   dim3 grid(B * nheads), block(N <= 64 ? 64 : N <= 128 ? 128 : N <= 192 ? 192 : 256);
   hipStream_t st = as_stream(stream);
   const float scale = 1.0f / sqrtf((float)dh);
+  if (mfma) {
+    block = dim3(64 * ((N + 31) / 32));
+    const bool vec = dh % 4 == 0 && qkv_ld % 4 == 0 && out_ld % 4 == 0 && aligned16(qkv) && aligned16(out);
+#define MMB_FWD_MFMA(DHV, VECV)                                                                                \
+  hipLaunchKernelGGL((attn_fwd_mfma_kernel<DHV, VECV>), grid, block, lds, st, N, H, nheads, dh, qkv, qkv_ld, maskf, \
+                     valid_is_zero, scale, out, out_ld, lse)
+    if (dh <= 16) { if (vec) MMB_FWD_MFMA(16, true); else MMB_FWD_MFMA(16, false); }
+    else { if (vec) MMB_FWD_MFMA(32, true); else MMB_FWD_MFMA(32, false); }
+#undef MMB_FWD_MFMA
+    return check_launch("mmb_attention_fwd");
+  }
   MMB_ATTN_DISPATCH(attn_fwd_kernel, N, H, nheads, dh, qkv, qkv_ld, maskf, valid_is_zero, scale, out, out_ld, lse);
   return check_launch("mmb_attention_fwd");
 }
@@ -355,12 +750,25 @@ extern "C" int mmb_attention_bwd(int B, int N, int H, int nheads, const float* q
                                  void* stream) {
   MMB_REQUIRE(qkv && maskf && out && dout && lse && dqkv, "mmb_attention_bwd: NULL argument");
   const int dh = nheads > 0 ? H / nheads : 0, dhp = pad_dh(dh);
-  const size_t lds = attn_lds_bytes(N, dhp, true);
+  const bool mfma = N > 0 && dh > 0 && attn_use_mfma(N, dh, true);
+  const size_t lds = mfma ? attn_mfma_lds_bytes(N, dh <= 16 ? 16 : 32, true) : attn_lds_bytes(N, dhp, true);
   if (int rc = attn_check("mmb_attention_bwd", B, N, H, nheads, qkv_ld, lds)) return rc;
   MMB_REQUIRE(out_ld >= H && dout_ld >= H && dqkv_ld >= 3 * (int64_t)H, "mmb_attention_bwd: row stride too small");
   dim3 grid(B * nheads), block(N <= 64 ? 64 : N <= 128 ? 128 : N <= 192 ? 192 : 256);
   hipStream_t st = as_stream(stream);
   const float scale = 1.0f / sqrtf((float)dh);
+  if (mfma) {
+    block = dim3(64 * ((N + 31) / 32));
+    const bool vec = dh % 4 == 0 && qkv_ld % 4 == 0 && out_ld % 4 == 0 && dout_ld % 4 == 0 && dqkv_ld % 4 == 0 &&
+                     aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv);
+#define MMB_BWD_MFMA(DHV, VECV)                                                                                \
+  hipLaunchKernelGGL((attn_bwd_mfma_kernel<DHV, VECV>), grid, block, lds, st, N, H, nheads, dh, qkv, qkv_ld, maskf, \
+                     valid_is_zero, scale, out, out_ld, dout, dout_ld, lse, dqkv, dqkv_ld)
+    if (dh <= 16) { if (vec) MMB_BWD_MFMA(16, true); else MMB_BWD_MFMA(16, false); }
+    else { if (vec) MMB_BWD_MFMA(32, true); else MMB_BWD_MFMA(32, false); }
+#undef MMB_BWD_MFMA
+    return check_launch("mmb_attention_bwd");
+  }
   MMB_ATTN_DISPATCH(attn_bwd_kernel, N, H, nheads, dh, qkv, qkv_ld, maskf, valid_is_zero, scale, out, out_ld, dout,
                     dout_ld, lse, dqkv, dqkv_ld);
   return check_launch("mmb_attention_bwd");

@@ -42,8 +42,12 @@ def make_mask(B, N, g):
 @pytest.mark.parametrize("B,N,H,nh", [(5, 16, 8, 2), (3, 11, 12, 2), (4, 150, 64, 4), (3, 150, 128, 4), (2, 200, 32, 8),
                                       (2, 70, 128, 2)])
 @pytest.mark.parametrize("valid_is_zero", [True, False])
-def test_attention_forward_backward(B, N, H, nh, valid_is_zero):
+@pytest.mark.parametrize("path", ["mfma", "valu"])
+def test_attention_forward_backward(B, N, H, nh, valid_is_zero, path, monkeypatch):
+    """path = mfma: the matrix-core kernels where they apply (head width <= 32, N <= 256), valu: the
+    one-query-per-thread kernels for every shape (what head width 64 always runs)."""
     from mmb_hip import ops
+    monkeypatch.setenv("MMB_ATTN_PATH", path)
     g = torch.Generator().manual_seed(B * 1000 + N + H)
     qkv = torch.randn(B, N, 3 * H, generator=g)
     mask = make_mask(B, N, g)

@@ -10,6 +10,8 @@
 // Inside a K chunk the MFMA k index is permuted (k = half*BK/2 + step) so that every lane
 // reads BK/2 CONTIGUOUS floats for its fragment (dwordx4 global loads, ds_read_b128).
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 #include <utility>
 
 namespace mmb {
@@ -85,31 +87,67 @@ __device__ inline float fetch_cat(const Segs& sg, int row, int jet, float m, int
 
 // common epilogue of one 32x32 accumulator tile (C/D layout of 32x32x2: col = lane&31,
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)):  y1 = act(z + b) + res1 [* row_scale];  y2 = dropout(post(y1)) + res2
-__device__ __forceinline__ void epilogue_tile(const f32x16& acc, int row0, int col, int half, int M, int Nout,
+// act over the 16 values of a tile, ONE uniform switch
+__device__ __forceinline__ void apply_act16(int act, f32x16& v) {
+  switch (act) {
+    case MMB_ACT_GELU: static_for<16>([&](auto ic) { v[decltype(ic)::v] = apply_act(MMB_ACT_GELU, v[decltype(ic)::v]); }); break;
+    case MMB_ACT_LRELU: static_for<16>([&](auto ic) { v[decltype(ic)::v] = apply_act(MMB_ACT_LRELU, v[decltype(ic)::v]); }); break;
+    case MMB_ACT_RELU: static_for<16>([&](auto ic) { v[decltype(ic)::v] = apply_act(MMB_ACT_RELU, v[decltype(ic)::v]); }); break;
+    case MMB_ACT_SELU: static_for<16>([&](auto ic) { v[decltype(ic)::v] = apply_act(MMB_ACT_SELU, v[decltype(ic)::v]); }); break;
+    default: break;
+  }
+}
+
+__device__ __forceinline__ void epilogue_tile(f32x16 v, int row0, int col, int half, int M, int Nout,
                                               const float* __restrict__ bias, int act,
                                               const float* __restrict__ residual, int64_t res_ld,
                                               const float* __restrict__ row_scale, float* __restrict__ Y,
                                               int64_t y_ld, float* __restrict__ pre_act, const Post& post) {
-  const bool col_ok = col < Nout;
-  const float bv = (bias && col_ok) ? bias[col] : 0.0f;
-  static_for<16>([&](auto ic) {
-    constexpr int i = decltype(ic)::v;
-    const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * half;
-    if (col_ok && row < M) {
-      float z = acc[i] + bv;
-      if (pre_act) pre_act[(int64_t)row * Nout + col] = z;
-      float y = apply_act(act, z);
-      if (residual) y += residual[(int64_t)row * res_ld + col];
-      if (row_scale) y *= row_scale[row];
-      if (Y) Y[(int64_t)row * y_ld + col] = y;
-      if (post.Y2) {
-        float y2 = apply_act(post.act, y);
-        if (post.drop_p > 0.0f) y2 = dropout_apply(y2, post.drop_p, post.seed, post.offset, (uint64_t)row * Nout + col);
-        if (post.res2) y2 += post.res2[(int64_t)row * post.res2_ld + col];
-        post.Y2[(int64_t)row * post.y2_ld + col] = y2;
-      }
-    }
-  });
+  // one pass per optional stream over the tile's 16 values (uniform branches OUTSIDE the element loops: the
+  // per-element form of this function compiled to ~500 branches and 60 live registers of addresses)
+  if (col >= Nout) return;
+  const int rbase = row0 + 4 * half;
+  auto row_of = [&](int i) { return rbase + (i & 3) + 8 * (i >> 2); };
+  const float bv = bias ? bias[col] : 0.0f;
+  static_for<16>([&](auto ic) { v[decltype(ic)::v] += bv; });
+  if (pre_act)
+    static_for<16>([&](auto ic) {
+      constexpr int i = decltype(ic)::v;
+      if (row_of(i) < M) pre_act[(int64_t)row_of(i) * Nout + col] = v[i];
+    });
+  apply_act16(act, v);
+  if (residual)
+    static_for<16>([&](auto ic) {
+      constexpr int i = decltype(ic)::v;
+      if (row_of(i) < M) v[i] += residual[(int64_t)row_of(i) * res_ld + col];
+    });
+  if (row_scale)
+    static_for<16>([&](auto ic) {
+      constexpr int i = decltype(ic)::v;
+      if (row_of(i) < M) v[i] *= row_scale[row_of(i)];
+    });
+  if (Y)
+    static_for<16>([&](auto ic) {
+      constexpr int i = decltype(ic)::v;
+      if (row_of(i) < M) Y[(int64_t)row_of(i) * y_ld + col] = v[i];
+    });
+  if (post.Y2) {
+    apply_act16(post.act, v);
+    if (post.drop_p > 0.0f)
+      static_for<16>([&](auto ic) {
+        constexpr int i = decltype(ic)::v;
+        v[i] = dropout_apply(v[i], post.drop_p, post.seed, post.offset, (uint64_t)row_of(i) * Nout + col);
+      });
+    if (post.res2)
+      static_for<16>([&](auto ic) {
+        constexpr int i = decltype(ic)::v;
+        if (row_of(i) < M) v[i] += post.res2[(int64_t)row_of(i) * post.res2_ld + col];
+      });
+    static_for<16>([&](auto ic) {
+      constexpr int i = decltype(ic)::v;
+      if (row_of(i) < M) post.Y2[(int64_t)row_of(i) * post.y2_ld + col] = v[i];
+    });
+  }
 }
 
 template <int WAVES, int NT, int BK, bool ALIGNED>
@@ -260,6 +298,119 @@ linear_cat_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restri
     epilogue_tile(acc[j], row0, col0 + j * 32 + r32, half, M, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld,
                   pre_act, post);
   });
+}
+
+// ---- large-M variant with the weight block RESIDENT in LDS ("row streaming") ---------------------------------
+// The per-particle layers are tall and skinny (M = 10^5 rows, K and Nout of 64..384): a 128-row block of the kernel
+// above lives for two or three K chunks, most of which it spends waiting for its first loads and at barriers.  Here
+// ONE block of 16 waves per CU stages its [NT*32 x K] weight block in LDS once (up to 160 KB) and after that single
+// barrier every wave streams 32-row tiles on its own: A fragments straight from global memory, the next chunk (or
+// the next tile's first chunk) in flight during the MFMAs and the epilogue.  Tiles are dealt to SIMDs (wave & 3),
+// not to waves, so that the matrix pipes -- the shared resource -- carry equal loads.
+template <int NT>
+__global__ void __launch_bounds__(1024)
+linear_stream_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restrict__ maskf,
+                     const float* __restrict__ W, int64_t w_ld, const float* __restrict__ bias, int Nout, int act,
+                     const float* __restrict__ residual, int64_t res_ld, const float* __restrict__ row_scale,
+                     float* __restrict__ Y, int64_t y_ld, float* __restrict__ pre_act, Post post) {
+  constexpr int BN = NT * 32;
+  constexpr int HALF = 16;                      // BK = 32
+  extern __shared__ __attribute__((aligned(16))) float Wl[];
+  const int KP = (K + 31) & ~31, PITCH = KP + 4;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, r32 = lane & 31;
+  const int col0 = blockIdx.y * BN;
+  for (int idx = tid; idx < BN * (KP / 4); idx += blockDim.x) {
+    const int o = idx / (KP / 4), gk = 4 * (idx - o * (KP / 4));
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col0 + o < Nout && gk < K) v = *reinterpret_cast<const float4*>(W + (int64_t)(col0 + o) * w_ld + gk);
+    *reinterpret_cast<float4*>(&Wl[o * PITCH + gk]) = v;
+  }
+  __syncthreads();                              // the only barrier: waves are on their own from here
+
+  const int nchunks = KP / 32, ntiles = (M + 31) / 32;
+  const int nsimd = gridDim.x * 4, tstep = nsimd * (blockDim.x >> 8);
+  int t = blockIdx.x * 4 + (wave & 3) + nsimd * (wave >> 2);
+  if (t >= ntiles) return;
+
+  int ld_row, jet;
+  float m;
+  float a_next[HALF];
+  float a_scale_next = 1.0f;
+  auto setup = [&](int tile) {
+    const int my_row = tile * 32 + r32;
+    ld_row = my_row < M ? my_row : M - 1;       // clamp loads; stores are guarded
+    jet = ld_row / rows_per_jet;
+    m = maskf ? maskf[ld_row] : 1.0f;
+  };
+  auto load_a = [&](int chunk) {                // (segments are HALF-aligned: the lane's 16 values live in one of them)
+    const int kh = chunk * 32 + half * HALF;
+    const float* src = nullptr;
+    float scale = 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < sg.n && kh >= sg.s[i].k_begin && kh < sg.s[i].k_begin + sg.s[i].width) {
+        const Seg& sgm = sg.s[i];
+        const int64_t base = (sgm.kind == MMB_SEG_ROW) ? (int64_t)ld_row * sgm.ld : (int64_t)jet * sgm.ld;
+        src = sgm.ptr + base + (kh - sgm.k_begin);
+        scale = (sgm.kind == MMB_SEG_JET_MASK) ? m : 1.0f;
+      }
+    }
+    if (src != nullptr) {
+#pragma unroll
+      for (int q = 0; q < HALF / 4; ++q) {
+        const float4 v = reinterpret_cast<const float4*>(src)[q];
+        a_next[4 * q + 0] = v.x; a_next[4 * q + 1] = v.y;
+        a_next[4 * q + 2] = v.z; a_next[4 * q + 3] = v.w;
+      }
+      a_scale_next = scale;
+    } else {
+      a_scale_next = 1.0f;
+#pragma unroll
+      for (int q = 0; q < HALF; ++q) a_next[q] = 0.0f;
+    }
+  };
+
+  setup(t);
+  load_a(0);
+  while (true) {
+    const int row0 = t * 32;
+    const int tn = t + tstep;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+    for (int c = 0; c < nchunks; ++c) {
+      float a_cur[HALF];
+#pragma unroll
+      for (int q = 0; q < HALF; ++q) a_cur[q] = a_next[q] * a_scale_next;
+      if (c + 1 < nchunks) load_a(c + 1);
+      const float* wbuf = Wl + c * 32 + half * HALF;
+#pragma unroll
+      for (int s4 = 0; s4 < HALF / 4; ++s4) {
+        float4 b[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const float4*>(&wbuf[(j * 32 + r32) * PITCH + 4 * s4]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[4 * s4 + 0], b[j].x, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[4 * s4 + 1], b[j].y, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[4 * s4 + 2], b[j].z, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[4 * s4 + 3], b[j].w, acc[j], 0, 0, 0);
+      }
+    }
+    static_for<NT>([&](auto jc) {
+      constexpr int j = decltype(jc)::v;
+      epilogue_tile(acc[j], row0, col0 + j * 32 + r32, half, M, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld,
+                    pre_act, post);
+    });
+    if (tn >= ntiles) break;
+    t = tn;
+    setup(t);                                   // (fetching before the epilogue would keep 16 more registers live
+    load_a(0);                                  //  across it: the other three waves of the SIMD cover this latency)
+  }
 }
 
 // ---- small-M variant (per-jet layers, M = B rows): split-K over the 4 waves of a block ----------
@@ -516,6 +667,21 @@ static void launch_linear(dim3 grid, hipStream_t st, int M, int rpj, const Segs&
                      maskf, W, w_ld, bias, Nout, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);
 }
 
+static int cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+  }
+  return n;
+}
+static bool stream_enabled() {                   // A/B switch for tests and profiles
+  const char* e = getenv("MMB_LINEAR_PATH");
+  return !(e && !strcmp(e, "tiled"));
+}
+
 }  // namespace mmb
 
 using namespace mmb;
@@ -584,6 +750,43 @@ extern "C" int mmb_linear_cat(int M, int rows_per_jet, int n_seg, const void* co
     return check_launch("mmb_linear_cat");
   }
   const bool small_m = M <= 4096;                // per-jet rows: one wave per block for parallelism
+  if (!small_m && al16 && stream_enabled()) {
+    // row-streaming kernel: the widest column block (4, 2, 1 tiles of 32) that pads Nout least and fits LDS
+    const int KP = (K + 31) & ~31;
+    int snt = 0;
+    int best_pad = 1 << 30;
+    for (int c = 2; c >= 1; c >>= 1) {           // (4 tiles per wave do not fit 128 registers beside the epilogue)
+      const int pad = (Nout + 32 * c - 1) / (32 * c) * (32 * c);
+      if ((size_t)32 * c * (KP + 4) * sizeof(float) <= 160 * 1024 && pad < best_pad) {
+        best_pad = pad;
+        snt = c;
+      }
+    }
+    if (snt) {
+      const int gy = best_pad / (32 * snt), ntiles = (M + 31) / 32, cus = cu_count();
+      int gx = cus / gy / 8 * 8;                 // same-x blocks (same rows, other columns) land on one XCD's L2
+      if (gx < 8) gx = cus / gy > 0 ? cus / gy : 1;
+      if (gx > (ntiles + 3) / 4) gx = (ntiles + 3) / 4;
+      const size_t lds = (size_t)32 * snt * (KP + 4) * sizeof(float);
+      dim3 g3(gx, gy);
+#define MMB_STREAM(NT_)                                                                                          \
+  do {                                                                                                           \
+    static bool attr_set = false;                                                                                \
+    if (!attr_set) {                                                                                             \
+      MMB_REQUIRE(hipFuncSetAttribute((const void*)linear_stream_kernel<NT_>,                                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,     \
+                  "mmb_linear_cat: cannot raise the dynamic LDS limit");                                         \
+      attr_set = true;                                                                                           \
+    }                                                                                                            \
+    hipLaunchKernelGGL((linear_stream_kernel<NT_>), g3, dim3(1024), lds, st, M, rows_per_jet, sg, K, maskf, W,   \
+                       w_ld, bias, Nout, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);              \
+  } while (0)
+      if (snt == 2) MMB_STREAM(2);
+      else MMB_STREAM(1);
+#undef MMB_STREAM
+      return check_launch("mmb_linear_cat");
+    }
+  }
   const int nt = Nout <= 32 ? 1 : (Nout <= 64 ? 2 : 4);
   const int bm = small_m ? 32 : 128;
   dim3 grid((M + bm - 1) / bm, (Nout + nt * 32 - 1) / (nt * 32));

@@ -177,8 +177,16 @@ def test_loss_fwd_bwd(ops):
     (300, 1, [20], [0], 8, None),                                # split-K, K below one slice, ragged Nout
     (1024, 1, [384], [0], 128, "gelu"),                          # split-K upper limit (S2 projection)
     (512, 1, [400], [0], 16, None),                              # beyond the split-K limit: layered small-M path
+    (40 * 150, 150, [64], [0], 192, "gelu"),                     # S4 in_proj: three column blocks of 64
+    (40 * 150, 150, [256], [0], 64, None),                       # S4 linear2
+    (4100, 1, [272], [0], 100, "lrelu"),                         # ragged everything, K % 32 = 16
+    (4200, 100, [1280, 32], [0, 1], 40, None),                   # K too wide for a resident weight block: tiled kernel
 ])
-def test_linear_cat(ops, M, N, widths, kinds, Nout, act):
+@pytest.mark.parametrize("path", ["stream", "tiled"])
+def test_linear_cat(ops, M, N, widths, kinds, Nout, act, path, monkeypatch):
+    """path: M > 4096 rows with 16-aligned segments run the row-streaming kernel (weight block resident in LDS)
+    unless MMB_LINEAR_PATH=tiled; every other shape runs the same kernel under both values."""
+    monkeypatch.setenv("MMB_LINEAR_PATH", path)
     g = torch.Generator().manual_seed(M + Nout)
     B = M // N
     segs_cpu, segs = [], []

@@ -45,5 +45,20 @@ def main():
         print(f"   max |valu - mfma|: out {do:.2e}  dqkv {dg:.2e} (scale {float(res['valu'][1].abs().max()):.2e})")
 
 
+def layernorm():
+    M = 1024 * 150
+    for D in (64, 128):
+        x = torch.randn(M, D, device="cuda")
+        gm, bt = torch.randn(D, device="cuda"), torch.randn(D, device="cuda")
+        dy, dx = torch.randn(M, D, device="cuda"), torch.empty(M, D, device="cuda")
+        dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+        y, stats = ops.layernorm_fwd(x, gm, bt, 1e-5, want_stats=True)
+        tf = timed(lambda: ops.layernorm_fwd(x, gm, bt, 1e-5, want_stats=True))
+        tb = timed(lambda: ops.layernorm_bwd(x, gm, stats, dy, dx, False, dg, db))
+        print(f"layernorm D={D}: fwd {tf:7.1f} us ({8.0 * M * D / tf * 1e-6:5.2f} TB/s)  "
+              f"bwd {tb:7.1f} us ({12.0 * M * D / tb * 1e-6:5.2f} TB/s)", flush=True)
+
+
 if __name__ == "__main__":
+    layernorm()
     main()

@@ -674,6 +674,108 @@ layernorm_bwd_kernel(int64_t M, int D, const float* __restrict__ x, int64_t x_ld
   }
 }
 
+// ---- LayerNorm, D = 64 / 128 / 256 (the transformer's widths): G = D/4 lanes per row, a float4 per lane, 64/G rows
+// per wave and U row groups in flight per iteration -- the one-row-per-wave kernels above keep 256 bytes per wave in
+// flight and are latency-bound at these widths (87 us for 39 MB in, 39 MB out)
+template <int G>
+__device__ __forceinline__ float group_sum(float s) {
+#pragma unroll
+  for (int o = G / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  return s;
+}
+
+template <int G>
+__global__ void __launch_bounds__(256)
+layernorm_fwd_vec_kernel(int64_t M, const float* __restrict__ x, int64_t x_ld, const float* __restrict__ gamma,
+                         const float* __restrict__ beta, float eps, float* __restrict__ y, int64_t y_ld,
+                         float* __restrict__ stats) {
+  constexpr int RPW = 64 / G, U = 4;
+  constexpr float INV_D = 1.0f / (4 * G);
+  const int lane = threadIdx.x & 63, sub = lane % G, rsub = lane / G;
+  const int64_t wave = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+  const float4 gm = reinterpret_cast<const float4*>(gamma)[sub], bt = reinterpret_cast<const float4*>(beta)[sub];
+  for (int64_t r0 = wave * (RPW * U); r0 < M; r0 += nw * (RPW * U)) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u * RPW + rsub;
+      v[u] = r < M ? *reinterpret_cast<const float4*>(x + r * x_ld + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u * RPW + rsub;
+      const float mu = group_sum<G>((v[u].x + v[u].y) + (v[u].z + v[u].w)) * INV_D;
+      const float dx = v[u].x - mu, dy = v[u].y - mu, dz = v[u].z - mu, dw = v[u].w - mu;
+      const float rstd = rsqrtf(group_sum<G>(fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, dw * dw)))) * INV_D + eps);
+      if (r < M) {
+        *reinterpret_cast<float4*>(y + r * y_ld + 4 * sub) =
+            make_float4(fmaf(dx * rstd, gm.x, bt.x), fmaf(dy * rstd, gm.y, bt.y), fmaf(dz * rstd, gm.z, bt.z),
+                        fmaf(dw * rstd, gm.w, bt.w));
+        if (stats && sub == 0) *reinterpret_cast<float2*>(stats + 2 * r) = make_float2(mu, rstd);
+      }
+    }
+  }
+}
+
+template <int G>
+__global__ void __launch_bounds__(256)
+layernorm_bwd_vec_kernel(int64_t M, const float* __restrict__ x, int64_t x_ld, const float* __restrict__ gamma,
+                         const float* __restrict__ stats, const float* __restrict__ dy, int64_t dy_ld,
+                         float* __restrict__ dx, int64_t dx_ld, int accumulate, float* __restrict__ dgamma,
+                         float* __restrict__ dbeta) {
+  constexpr int RPW = 64 / G, U = 2;
+  constexpr float INV_D = 1.0f / (4 * G);
+  __shared__ float4 red[2][4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane % G, rsub = lane / G;
+  const int64_t wave = blockIdx.x * (int64_t)4 + w, nw = (int64_t)gridDim.x * 4;
+  const float4 gm = reinterpret_cast<const float4*>(gamma)[sub];
+  float4 pg = make_float4(0.f, 0.f, 0.f, 0.f), pb = pg;
+  for (int64_t r0 = wave * (RPW * U); r0 < M; r0 += nw * (RPW * U)) {
+    float4 xv[U], dv[U], old[U];
+    float2 st[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u * RPW + rsub;
+      const bool ok = r < M;
+      xv[u] = ok ? *reinterpret_cast<const float4*>(x + r * x_ld + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dv[u] = ok ? *reinterpret_cast<const float4*>(dy + r * dy_ld + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+      st[u] = ok ? *reinterpret_cast<const float2*>(stats + 2 * r) : make_float2(0.f, 0.f);
+      if (accumulate) old[u] = ok ? *reinterpret_cast<const float4*>(dx + r * dx_ld + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u * RPW + rsub;
+      const float mu = st[u].x, rstd = st[u].y;
+      const float4 xh = make_float4((xv[u].x - mu) * rstd, (xv[u].y - mu) * rstd, (xv[u].z - mu) * rstd,
+                                    (xv[u].w - mu) * rstd);
+      const float4 d = dv[u];
+      const float4 g = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+      pg.x = fmaf(d.x, xh.x, pg.x); pg.y = fmaf(d.y, xh.y, pg.y); pg.z = fmaf(d.z, xh.z, pg.z); pg.w = fmaf(d.w, xh.w, pg.w);
+      pb.x += d.x; pb.y += d.y; pb.z += d.z; pb.w += d.w;
+      const float s1 = group_sum<G>((g.x + g.y) + (g.z + g.w)) * INV_D;
+      const float s2 = group_sum<G>(fmaf(g.x, xh.x, fmaf(g.y, xh.y, fmaf(g.z, xh.z, g.w * xh.w)))) * INV_D;
+      if (r < M) {
+        float4 o = make_float4(rstd * (g.x - s1 - xh.x * s2), rstd * (g.y - s1 - xh.y * s2),
+                               rstd * (g.z - s1 - xh.z * s2), rstd * (g.w - s1 - xh.w * s2));
+        if (accumulate) { o.x += old[u].x; o.y += old[u].y; o.z += old[u].z; o.w += old[u].w; }
+        *reinterpret_cast<float4*>(dx + r * dx_ld + 4 * sub) = o;
+      }
+    }
+  }
+  red[0][w][lane] = pg;
+  red[1][w][lane] = pb;
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * 4 * G; c += 256) {           // one thread per (array, column)
+    const int which = c / (4 * G), col = c - which * (4 * G), sb = col >> 2, comp = col & 3;
+    float s = 0.0f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww)
+#pragma unroll
+      for (int rs = 0; rs < RPW; ++rs) s += reinterpret_cast<const float*>(&red[which][ww][rs * G + sb])[comp];
+    atomicAdd((which ? dbeta : dgamma) + col, s);
+  }
+}
+
 // dst[i] (+)= sum_r src[r*stride + i]
 __global__ void __launch_bounds__(256)
 sum_replicas_kernel(int64_t n, int R, int64_t stride, const float* __restrict__ src, float* __restrict__ dst,
@@ -779,6 +881,17 @@ extern "C" int mmb_layernorm_fwd(int64_t M, int D, const float* x, int64_t x_ld,
   MMB_REQUIRE(M > 0 && D > 0, "mmb_layernorm_fwd: empty shape");
   MMB_REQUIRE(x && gamma && beta && y, "mmb_layernorm_fwd: NULL argument");
   MMB_REQUIRE(x_ld >= D && y_ld >= D, "mmb_layernorm_fwd: row stride < D");
+  if ((D == 64 || D == 128 || D == 256) && x_ld % 4 == 0 && y_ld % 4 == 0 && aligned16(x) && aligned16(y) &&
+      aligned16(gamma) && aligned16(beta) && (!stats || (reinterpret_cast<uintptr_t>(stats) & 7) == 0)) {
+    const int rpb = 4 * (256 / D) * 4 * 4;         // rows per block and iteration: 4 waves x 64/G rows x U = 4
+    const int64_t nb = (M + rpb - 1) / rpb;
+    const dim3 grid((unsigned)(nb > 2048 ? 2048 : nb));
+    hipStream_t st = as_stream(stream);
+#define MMB_LN_F(G_) hipLaunchKernelGGL((layernorm_fwd_vec_kernel<G_>), grid, dim3(256), 0, st, M, x, x_ld, gamma, beta, eps, y, y_ld, stats)
+    if (D == 64) MMB_LN_F(16); else if (D == 128) MMB_LN_F(32); else MMB_LN_F(64);
+#undef MMB_LN_F
+    return check_launch("mmb_layernorm_fwd");
+  }
   const int64_t blocks = (M + 3) / 4;
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0,
                      as_stream(stream), M, D, x, x_ld, gamma, beta, eps, y, y_ld, stats);
@@ -792,6 +905,17 @@ extern "C" int mmb_layernorm_bwd(int64_t M, int D, const float* x, int64_t x_ld,
   MMB_REQUIRE(D <= 64 * LN_MAXC, "mmb_layernorm_bwd: D=%d > %d is not supported", D, 64 * LN_MAXC);
   MMB_REQUIRE(x && gamma && stats && dy && dx && dgamma && dbeta, "mmb_layernorm_bwd: NULL argument");
   MMB_REQUIRE(x_ld >= D && dy_ld >= D && dx_ld >= D, "mmb_layernorm_bwd: row stride < D");
+  if ((D == 64 || D == 128 || D == 256) && x_ld % 4 == 0 && dy_ld % 4 == 0 && dx_ld % 4 == 0 && aligned16(x) &&
+      aligned16(dy) && aligned16(dx) && aligned16(gamma) && (reinterpret_cast<uintptr_t>(stats) & 7) == 0) {
+    const int rpb = 4 * (256 / D) * 4 * 2;         // 4 waves x 64/G rows x U = 2
+    const int64_t nb = (M + rpb - 1) / rpb;
+    const dim3 grid((unsigned)(nb > 1024 ? 1024 : nb));   // <= 1024 same-address atomics per column
+    hipStream_t st = as_stream(stream);
+#define MMB_LN_B(G_) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<G_>), grid, dim3(256), 0, st, M, x, x_ld, gamma, stats, dy, dy_ld, dx, dx_ld, accumulate, dgamma, dbeta)
+    if (D == 64) MMB_LN_B(16); else if (D == 128) MMB_LN_B(32); else MMB_LN_B(64);
+#undef MMB_LN_B
+    return check_launch("mmb_layernorm_bwd");
+  }
   const int64_t blocks = (M + 63) / 64;            // 16 rows per wave: few atomics per column
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0,
                      as_stream(stream), M, D, x, x_ld, gamma, stats, dy, dy_ld, dx, dx_ld, accumulate, dgamma, dbeta);

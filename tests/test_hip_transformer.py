@@ -84,7 +84,7 @@ def test_attention_rejects_bad_shapes():
         ops.attention_fwd(torch.zeros(16, 24), mi, 2)                               # CPU tensor: no fallback
 
 
-@pytest.mark.parametrize("M,D", [(7, 8), (1000, 64), (19200, 128), (33, 200), (5, 512)])
+@pytest.mark.parametrize("M,D", [(7, 8), (1000, 64), (19200, 128), (33, 200), (5, 512), (301, 256), (4099, 64)])
 def test_layernorm_forward_backward(M, D):
     from mmb_hip import ops
     g = torch.Generator().manual_seed(M + D)

@@ -95,10 +95,12 @@ class Arena:
         return out
 
 
-def _acc_param(p, g):
-    g = g.reshape(p.shape)
+def _acc_param(p, g, shared=False):
+    """p.grad += g (torch.autograd semantics).  shared: g lives in memory that is re-used (the arena, a slice of a
+    wider buffer), so it is copied when it has to BECOME the gradient -- and only then."""
+    g = g.reshape(p.shape) if g.is_contiguous() else g
     if p.grad is None:
-        p.grad = g.clone() if g.untyped_storage().data_ptr() == p.untyped_storage().data_ptr() else g
+        p.grad = g.clone() if shared or g.untyped_storage().data_ptr() == p.untyped_storage().data_ptr() else g
     else:
         p.grad.add_(g)
 
@@ -195,18 +197,34 @@ def plain_param_grads(spec, segs, dZ, S, Sm, arena):
         else:
             ops.grad_weight_rows(t, Sm, dWs, None)
         koff += Ks
+    def direct(q):                                      # an existing contiguous .grad takes the replica sum itself
+        return q is not None and q.grad is not None and q.grad.is_contiguous()
+
+    own = False
     if R > 1:
-        dW = ops.sum_replicas(dWr, torch.empty(Nout * Kall, dtype=torch.float32, device=dZ.device)).view(Nout, Kall)
-        db = ops.sum_replicas(dbr, torch.empty(Nout, dtype=torch.float32, device=dZ.device))
+        w0 = spec.parts[0][0]
+        if len(spec.parts) == 1 and direct(w0):
+            ops.sum_replicas(dWr, w0.grad.view(-1), accumulate=True)
+            dW = None
+        else:
+            dW = ops.sum_replicas(dWr, torch.empty(Nout * Kall, dtype=torch.float32, device=dZ.device)).view(Nout, Kall)
+            own = len(spec.parts) == 1
+        if len(spec.biases) == 1 and direct(spec.biases[0]):
+            ops.sum_replicas(dbr, spec.biases[0].grad.view(-1), accumulate=True)
+            db = None
+        else:
+            db = ops.sum_replicas(dbr, torch.empty(Nout, dtype=torch.float32, device=dZ.device))
     else:
         db = dbr[0]
     koff = 0
-    for w, k in spec.parts:
-        if w is not None:
-            _acc_param(w, dW[:, koff:koff + k].contiguous() if len(spec.parts) > 1 else dW.clone())
-        koff += k
-    for i, b in enumerate(spec.biases):
-        _acc_param(b, db.clone())
+    if dW is not None:
+        for w, k in spec.parts:
+            if w is not None:
+                _acc_param(w, dW[:, koff:koff + k] if len(spec.parts) > 1 else dW, shared=not own)
+            koff += k
+    if db is not None:
+        for i, b in enumerate(spec.biases):
+            _acc_param(b, db, shared=True)
     return W
 
 
@@ -217,7 +235,10 @@ def _linear_bwd(e, store, produced, mi, seed, arena, touched):
         return
     ref = y1 if y1 is not None else y2
     M, Nout = ref.shape
-    dZ = ops.act_bwd(M, Nout, gY1, gY2, y1, y2, res2, pre, act, post, p, seed, off)
+    if act is None and gY2 is None:
+        dZ = gY1                        # identity first stage, no gradient through the second: nothing to compute
+    else:
+        dZ = ops.act_bwd(M, Nout, gY1, gY2, y1, y2, res2, pre, act, post, p, seed, off)
     if res2 is not None and gY2 is not None and GradStore._key(res2) in produced:
         store.add(res2, gY2)            # y2's gradient is final here: nothing reads it after its producer
     if res1 is not None and GradStore._key(res1) in produced:
@@ -274,8 +295,8 @@ def _ln_bwd(e, store, produced, arena):
     else:
         gx, fresh = torch.empty_like(x), True
     ops.layernorm_bwd(x, norm.weight.detach(), stats, g, gx, not fresh, dgamma, dbeta)
-    _acc_param(norm.weight, dgamma.clone())
-    _acc_param(norm.bias, dbeta.clone())
+    _acc_param(norm.weight, dgamma, shared=True)
+    _acc_param(norm.bias, dbeta, shared=True)
 
 
 def _embed_bwd(e, store, mi):

@@ -32,7 +32,10 @@ def main():
     M, N = 1024 * 150, 150
     g = torch.Generator().manual_seed(0)
     tot = 0.0
+    only = os.environ.get("MMB_BENCH_SHAPE")                     # "K,N": one shape (for counter passes)
     for K, Nout, res, act in SHAPES:
+        if only and only != f"{K},{Nout}":
+            continue
         x = torch.randn(M, K, generator=g).cuda()
         W = (torch.randn(Nout, K, generator=g) / K ** 0.5).cuda()
         b = torch.randn(Nout, generator=g).cuda()

@@ -98,56 +98,71 @@ __device__ __forceinline__ void apply_act16(int act, f32x16& v) {
   }
 }
 
-__device__ __forceinline__ void epilogue_tile(f32x16 v, int row0, int col, int half, int M, int Nout,
-                                              const float* __restrict__ bias, int act,
-                                              const float* __restrict__ residual, int64_t res_ld,
-                                              const float* __restrict__ row_scale, float* __restrict__ Y,
-                                              int64_t y_ld, float* __restrict__ pre_act, const Post& post) {
-  // one pass per optional stream over the tile's 16 values (uniform branches OUTSIDE the element loops: the
-  // per-element form of this function compiled to ~500 branches and 60 live registers of addresses)
-  if (col >= Nout) return;
+template <bool FULL>                             // FULL: all 32 rows of the tile exist (no per-row guards: the
+__device__ __forceinline__ void                  // loads of a stream are then issued back to back, one wait)
+epilogue_tile_body(f32x16 v, int row0, int col, int half, int M, int Nout, const float* __restrict__ bias, int act,
+                   const float* __restrict__ residual, int64_t res_ld, const float* __restrict__ row_scale,
+                   float* __restrict__ Y, int64_t y_ld, float* __restrict__ pre_act, const Post& post) {
+  // one pass per optional stream over the tile's 16 values (uniform branches OUTSIDE the element loops), each
+  // stream addressed from ONE 64-bit base per lane plus compile-time multiples of its row stride
   const int rbase = row0 + 4 * half;
-  auto row_of = [&](int i) { return rbase + (i & 3) + 8 * (i >> 2); };
+  const int nrow = M - rbase;                  // rows of this lane's 16 that exist: offsets (i&3) + 8*(i>>2) < nrow
+  auto load16 = [&](const float* base, int64_t ld, f32x16& r) {
+    const float* p = base + (int64_t)rbase * ld + col;
+    static_for<16>([&](auto ic) {
+      constexpr int i = decltype(ic)::v;
+      constexpr int off = (i & 3) + 8 * (i >> 2);
+      r[i] = (FULL || off < nrow) ? p[off * ld] : 0.0f;
+    });
+  };
+  auto store16 = [&](float* base, int64_t ld, const f32x16& r) {
+    float* p = base + (int64_t)rbase * ld + col;
+    static_for<16>([&](auto ic) {
+      constexpr int i = decltype(ic)::v;
+      constexpr int off = (i & 3) + 8 * (i >> 2);
+      if (FULL || off < nrow) p[off * ld] = r[i];
+    });
+  };
+  f32x16 t;
   const float bv = bias ? bias[col] : 0.0f;
   static_for<16>([&](auto ic) { v[decltype(ic)::v] += bv; });
-  if (pre_act)
-    static_for<16>([&](auto ic) {
-      constexpr int i = decltype(ic)::v;
-      if (row_of(i) < M) pre_act[(int64_t)row_of(i) * Nout + col] = v[i];
-    });
+  if (pre_act) store16(pre_act, (int64_t)Nout, v);
   apply_act16(act, v);
-  if (residual)
-    static_for<16>([&](auto ic) {
-      constexpr int i = decltype(ic)::v;
-      if (row_of(i) < M) v[i] += residual[(int64_t)row_of(i) * res_ld + col];
-    });
-  if (row_scale)
-    static_for<16>([&](auto ic) {
-      constexpr int i = decltype(ic)::v;
-      if (row_of(i) < M) v[i] *= row_scale[row_of(i)];
-    });
-  if (Y)
-    static_for<16>([&](auto ic) {
-      constexpr int i = decltype(ic)::v;
-      if (row_of(i) < M) Y[(int64_t)row_of(i) * y_ld + col] = v[i];
-    });
+  if (residual) {
+    load16(residual, res_ld, t);
+    v += t;
+  }
+  if (row_scale) {
+    load16(row_scale - col, (int64_t)1, t);
+    v *= t;
+  }
+  if (Y) store16(Y, y_ld, v);
   if (post.Y2) {
     apply_act16(post.act, v);
     if (post.drop_p > 0.0f)
       static_for<16>([&](auto ic) {
         constexpr int i = decltype(ic)::v;
-        v[i] = dropout_apply(v[i], post.drop_p, post.seed, post.offset, (uint64_t)row_of(i) * Nout + col);
+        v[i] = dropout_apply(v[i], post.drop_p, post.seed, post.offset,
+                             (uint64_t)(rbase + (i & 3) + 8 * (i >> 2)) * Nout + col);
       });
-    if (post.res2)
-      static_for<16>([&](auto ic) {
-        constexpr int i = decltype(ic)::v;
-        if (row_of(i) < M) v[i] += post.res2[(int64_t)row_of(i) * post.res2_ld + col];
-      });
-    static_for<16>([&](auto ic) {
-      constexpr int i = decltype(ic)::v;
-      if (row_of(i) < M) post.Y2[(int64_t)row_of(i) * post.y2_ld + col] = v[i];
-    });
+    if (post.res2) {
+      load16(post.res2, post.res2_ld, t);
+      v += t;
+    }
+    store16(post.Y2, post.y2_ld, v);
   }
+}
+
+__device__ __forceinline__ void epilogue_tile(const f32x16& v, int row0, int col, int half, int M, int Nout,
+                                              const float* __restrict__ bias, int act,
+                                              const float* __restrict__ residual, int64_t res_ld,
+                                              const float* __restrict__ row_scale, float* __restrict__ Y,
+                                              int64_t y_ld, float* __restrict__ pre_act, const Post& post) {
+  if (col >= Nout) return;
+  if (row0 + 32 <= M)
+    epilogue_tile_body<true>(v, row0, col, half, M, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);
+  else
+    epilogue_tile_body<false>(v, row0, col, half, M, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);
 }
 
 template <int WAVES, int NT, int BK, bool ALIGNED>
@@ -410,6 +425,182 @@ linear_stream_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __res
     t = tn;
     setup(t);                                   // (fetching before the epilogue would keep 16 more registers live
     load_a(0);                                  //  across it: the other three waves of the SIMD cover this latency)
+  }
+}
+
+// ---- the row-streaming kernel on the bf16 matrix cores: fp32 products as six bf16-plane products -------------
+// Same structure as linear_stream_kernel; every fp32 value is split EXACTLY into three bf16 planes (hi + mid + lo,
+// 24 mantissa bits) and X W^T = Xl Wh + Xm Wm + Xh Wl + Xm Wh + Xh Wm + Xh Wh (each bf16 x bf16 product is exact in
+// fp32, fp32 accumulation, small terms first; the three dropped products are below 2^-24 of the result) -- the scheme
+// of the fused kernels (fused_common.h: mma_x).  Six v_mfma_f32_32x32x16_bf16 retire 16 k-values in 192 cycles
+// against 512 for eight v_mfma_f32_32x32x2_f32.  The weight block is split once, when it is staged into LDS
+// (three bf16 arrays [NT*32][K + 8]); an activation value is split once per column block, in registers.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+  const bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ void split8(const float* v, bf16x8& h, bf16x8& m, bf16x8& l) {
+  uint32_t ph[4], pm[4], pq[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = v[2 * j], b = v[2 * j + 1];
+    ph[j] = pk_bf16(a, b);
+    const float ra = a - __builtin_bit_cast(float, ph[j] << 16), rb = b - __builtin_bit_cast(float, ph[j] & 0xFFFF0000u);
+    pm[j] = pk_bf16(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, pm[j] << 16), sb = rb - __builtin_bit_cast(float, pm[j] & 0xFFFF0000u);
+    pq[j] = pk_bf16(sa, sb);
+  }
+  const u32x4 H = {ph[0], ph[1], ph[2], ph[3]}, M = {pm[0], pm[1], pm[2], pm[3]}, L = {pq[0], pq[1], pq[2], pq[3]};
+  h = __builtin_bit_cast(bf16x8, H);
+  m = __builtin_bit_cast(bf16x8, M);
+  l = __builtin_bit_cast(bf16x8, L);
+}
+
+template <int NT, int THREADS, bool SIMPLE>   // SIMPLE: one ROW segment (no segment search, no scale)
+__global__ void __launch_bounds__(THREADS)
+linear_stream_x6_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restrict__ maskf,
+                        const float* __restrict__ W, int64_t w_ld, const float* __restrict__ bias, int Nout, int act,
+                        const float* __restrict__ residual, int64_t res_ld, const float* __restrict__ row_scale,
+                        float* __restrict__ Y, int64_t y_ld, float* __restrict__ pre_act, Post post) {
+  constexpr int BN = NT * 32;
+  constexpr int HALF = 16;                      // a lane's share of a 32-wide K chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned short Wp[];     // [3][BN][PK] bf16
+  const int KP = (K + 63) & ~63, PK = KP + 8;    // K chunks of 32 come in PAIRS (buffers A, B): pad to 64
+  const int PLANE = BN * PK;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, r32 = lane & 31;
+  const int col0 = blockIdx.y * BN;
+  for (int idx = tid; idx < BN * (KP / 4); idx += blockDim.x) {
+    const int o = idx / (KP / 4), gk = 4 * (idx - o * (KP / 4));
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col0 + o < Nout && gk < K) v = *reinterpret_cast<const float4*>(W + (int64_t)(col0 + o) * w_ld + gk);
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    uint32_t ph[2], pm[2], pq[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float a = f[2 * j], b = f[2 * j + 1];
+      ph[j] = pk_bf16(a, b);
+      const float ra = a - __builtin_bit_cast(float, ph[j] << 16), rb = b - __builtin_bit_cast(float, ph[j] & 0xFFFF0000u);
+      pm[j] = pk_bf16(ra, rb);
+      const float sa = ra - __builtin_bit_cast(float, pm[j] << 16), sb = rb - __builtin_bit_cast(float, pm[j] & 0xFFFF0000u);
+      pq[j] = pk_bf16(sa, sb);
+    }
+    unsigned short* dst = Wp + o * PK + gk;
+    *reinterpret_cast<uint2*>(dst) = make_uint2(ph[0], ph[1]);
+    *reinterpret_cast<uint2*>(dst + PLANE) = make_uint2(pm[0], pm[1]);
+    *reinterpret_cast<uint2*>(dst + 2 * PLANE) = make_uint2(pq[0], pq[1]);
+  }
+  __syncthreads();                              // the only barrier
+
+  const int nchunks = KP / 32, npairs = KP / 64, ntiles = (M + 31) / 32;
+  const int nsimd = gridDim.x * 4, tstep = nsimd * (blockDim.x >> 8);
+  int t = blockIdx.x * 4 + (wave & 3) + nsimd * (wave >> 2);
+  if (t >= ntiles) return;
+
+  // The (tile, chunk) sequence of this wave is walked by TWO cursors: the fetch cursor runs two chunks ahead of the
+  // compute cursor (buffers A and B, filled alternately), across tile boundaries -- 128 bytes per lane in flight,
+  // which is what a CU needs outstanding to keep its share of HBM busy with 8..12 waves.
+  int ld_row, jet;
+  float m;
+  int ft = t, fc = 0;                            // fetch cursor
+  auto setup = [&](int tile) {
+    const int my_row = tile * 32 + r32;
+    ld_row = my_row < M ? my_row : M - 1;
+    jet = ld_row / rows_per_jet;
+    m = (!SIMPLE && maskf) ? maskf[ld_row] : 1.0f;
+  };
+  // branch-free: ALWAYS four 16-byte loads (past the last tile the previous rows are fetched again, past K the
+  // start of the row -- both land in valid memory and are multiplied by 0), so that the number of loads in flight
+  // is static and the compiler can wait for the OLDER buffer only (vmcnt(4)) instead of draining the queue
+  const bool kfull = SIMPLE && (K & 31) == 0;    // then every chunk is whole and bscale is not needed at all
+  auto fetch = [&](float (&buf)[HALF], float& bscale) __attribute__((always_inline)) {
+    const int kh = fc * 32 + half * HALF;
+    const float* src;
+    float scale = ft < ntiles ? 1.0f : 0.0f;
+    if constexpr (SIMPLE) {
+      const bool in = kh < K;
+      src = sg.s[0].ptr + (int64_t)ld_row * sg.s[0].ld + (in ? kh : 0);
+      if (!in) scale = 0.0f;
+    } else {
+      src = sg.s[0].ptr + ((sg.s[0].kind == MMB_SEG_ROW) ? (int64_t)ld_row * sg.s[0].ld : (int64_t)jet * sg.s[0].ld);
+      float sc = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < sg.n && kh >= sg.s[i].k_begin && kh < sg.s[i].k_begin + sg.s[i].width) {
+          const Seg& sgm = sg.s[i];
+          const int64_t base = (sgm.kind == MMB_SEG_ROW) ? (int64_t)ld_row * sgm.ld : (int64_t)jet * sgm.ld;
+          src = sgm.ptr + base + (kh - sgm.k_begin);
+          sc = (sgm.kind == MMB_SEG_JET_MASK) ? m : 1.0f;
+        }
+      }
+      scale *= sc;
+    }
+#pragma unroll
+    for (int q = 0; q < HALF / 4; ++q) {
+      const float4 v = reinterpret_cast<const float4*>(src)[q];
+      buf[4 * q + 0] = v.x; buf[4 * q + 1] = v.y;
+      buf[4 * q + 2] = v.z; buf[4 * q + 3] = v.w;
+    }
+    bscale = scale;
+    if (++fc == nchunks) {
+      fc = 0;
+      ft += tstep;
+      if (ft < ntiles) setup(ft);
+    }
+  };
+
+  f32x16 acc[NT];
+  auto zero_acc = [&]() __attribute__((always_inline)) {                        // (static_for: constant indices keep acc in registers)
+    static_for<NT>([&](auto jc) { static_for<16>([&](auto ic) { acc[decltype(jc)::v][decltype(ic)::v] = 0.0f; }); });
+  };
+  auto consume = [&](float (&buf)[HALF], float& bscale, int cc) __attribute__((always_inline)) {   // (else acc lives in scratch)
+    bf16x8 ahs[2], ams[2], als[2];               // split first: the buffer is free for the next fetch, no copy
+    if (!kfull) {
+#pragma unroll
+      for (int q = 0; q < HALF; ++q) buf[q] *= bscale;
+    }
+    split8(buf, ahs[0], ams[0], als[0]);
+    split8(buf + 8, ahs[1], ams[1], als[1]);
+    fetch(buf, bscale);
+    const unsigned short* wb = Wp + r32 * PK + cc * 32 + half * HALF;
+#pragma unroll
+    for (int s8 = 0; s8 < 2; ++s8) {
+      const bf16x8 ah = ahs[s8], am = ams[s8], al = als[s8];
+      static_for<NT>([&](auto jc) {
+        constexpr int j = decltype(jc)::v;
+        const unsigned short* wj = wb + j * 32 * PK + 8 * s8;
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wj));
+        const bf16x8 bm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wj + PLANE));
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wj + 2 * PLANE));
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+      });
+    }
+  };
+
+  float bufA[HALF], bufB[HALF];
+  float scaleA = 1.0f, scaleB = 1.0f;
+  setup(t);
+  fetch(bufA, scaleA);
+  fetch(bufB, scaleB);
+  for (; t < ntiles; t += tstep) {
+    zero_acc();
+    for (int p = 0; p < npairs; ++p) {
+      consume(bufA, scaleA, 2 * p);
+      consume(bufB, scaleB, 2 * p + 1);
+    }
+    const int row0 = t * 32;
+    static_for<NT>([&](auto jc) {
+      constexpr int j = decltype(jc)::v;
+      epilogue_tile(acc[j], row0, col0 + j * 32 + r32, half, M, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld,
+                    pre_act, post);
+    });
   }
 }
 
@@ -677,9 +868,13 @@ static int cu_count() {
   }
   return n;
 }
-static bool stream_enabled() {                   // A/B switch for tests and profiles
+// large-M kernel choice (A/B switch for tests and profiles): MMB_LINEAR_PATH = tiled (0) | stream (1: row streaming
+// on the fp32 MFMA) | x6 (2, the default: row streaming, six bf16-plane products)
+static int linear_path() {
   const char* e = getenv("MMB_LINEAR_PATH");
-  return !(e && !strcmp(e, "tiled"));
+  if (e && !strcmp(e, "tiled")) return 0;
+  if (e && !strcmp(e, "stream")) return 1;
+  return 2;
 }
 
 }  // namespace mmb
@@ -750,14 +945,21 @@ extern "C" int mmb_linear_cat(int M, int rows_per_jet, int n_seg, const void* co
     return check_launch("mmb_linear_cat");
   }
   const bool small_m = M <= 4096;                // per-jet rows: one wave per block for parallelism
-  if (!small_m && al16 && stream_enabled()) {
-    // row-streaming kernel: the widest column block (4, 2, 1 tiles of 32) that pads Nout least and fits LDS
-    const int KP = (K + 31) & ~31;
+  const int lpath = linear_path();
+  if (!small_m && al16 && lpath != 0) {
+    // row-streaming kernels: the widest column block (tiles of 32 columns) that pads Nout least and fits LDS
+    const bool x6 = lpath == 2;
+    const int KP = (K + 31) & ~31, KP2 = (K + 63) & ~63;
+    auto lds_of = [&](int c) {
+      return x6 ? (size_t)3 * 32 * c * (KP2 + 8) * sizeof(unsigned short) : (size_t)32 * c * (KP + 4) * sizeof(float);
+    };
     int snt = 0;
     int best_pad = 1 << 30;
-    for (int c = 2; c >= 1; c >>= 1) {           // (4 tiles per wave do not fit 128 registers beside the epilogue)
+    int cmax = x6 ? 4 : 2;                       // (fp32 MFMA: 4 tiles per wave do not fit 128 registers)
+    if (const char* e = getenv("MMB_X6_NT")) cmax = atoi(e) >= 1 && atoi(e) <= cmax ? atoi(e) : cmax;   // tuning knob
+    for (int c = cmax; c >= 1; c >>= 1) {
       const int pad = (Nout + 32 * c - 1) / (32 * c) * (32 * c);
-      if ((size_t)32 * c * (KP + 4) * sizeof(float) <= 160 * 1024 && pad < best_pad) {
+      if (lds_of(c) <= 160 * 1024 && pad < best_pad) {
         best_pad = pad;
         snt = c;
       }
@@ -767,22 +969,29 @@ extern "C" int mmb_linear_cat(int M, int rows_per_jet, int n_seg, const void* co
       int gx = cus / gy / 8 * 8;                 // same-x blocks (same rows, other columns) land on one XCD's L2
       if (gx < 8) gx = cus / gy > 0 ? cus / gy : 1;
       if (gx > (ntiles + 3) / 4) gx = (ntiles + 3) / 4;
-      const size_t lds = (size_t)32 * snt * (KP + 4) * sizeof(float);
+      const size_t lds = lds_of(snt);
       dim3 g3(gx, gy);
-#define MMB_STREAM(NT_)                                                                                          \
+#define MMB_STREAM(KERNEL, THREADS_)                                                                             \
   do {                                                                                                           \
     static bool attr_set = false;                                                                                \
     if (!attr_set) {                                                                                             \
-      MMB_REQUIRE(hipFuncSetAttribute((const void*)linear_stream_kernel<NT_>,                                    \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,     \
+      MMB_REQUIRE(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize,           \
+                                      160 * 1024) == hipSuccess,                                                 \
                   "mmb_linear_cat: cannot raise the dynamic LDS limit");                                         \
       attr_set = true;                                                                                           \
     }                                                                                                            \
-    hipLaunchKernelGGL((linear_stream_kernel<NT_>), g3, dim3(1024), lds, st, M, rows_per_jet, sg, K, maskf, W,   \
-                       w_ld, bias, Nout, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);              \
+    hipLaunchKernelGGL(KERNEL, g3, dim3(THREADS_), lds, st, M, rows_per_jet, sg, K, maskf, W, w_ld, bias, Nout,  \
+                       act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);                                \
   } while (0)
-      if (snt == 2) MMB_STREAM(2);
-      else MMB_STREAM(1);
+      if (x6) {                                  // wider column blocks need more registers: fewer waves per block
+        const bool simple = n_seg == 1 && seg_kind[0] == MMB_SEG_ROW;
+        if (snt == 4) { if (simple) MMB_STREAM((linear_stream_x6_kernel<4, 512, true>), 512); else MMB_STREAM((linear_stream_x6_kernel<4, 512, false>), 512); }
+        else if (snt == 2) { if (simple) MMB_STREAM((linear_stream_x6_kernel<2, 768, true>), 768); else MMB_STREAM((linear_stream_x6_kernel<2, 768, false>), 768); }
+        else { if (simple) MMB_STREAM((linear_stream_x6_kernel<1, 768, true>), 768); else MMB_STREAM((linear_stream_x6_kernel<1, 768, false>), 768); }
+      } else {
+        if (snt == 2) MMB_STREAM((linear_stream_kernel<2>), 1024);
+        else MMB_STREAM((linear_stream_kernel<1>), 1024);
+      }
 #undef MMB_STREAM
       return check_launch("mmb_linear_cat");
     }

@@ -289,14 +289,20 @@ def _ln_bwd(e, store, produced, arena):
     if g is None:
         return
     D = x.shape[1]
-    dgamma, dbeta = arena.take((D,)), arena.take((D,))
+    gw, gb = norm.weight.grad, norm.bias.grad
+    direct = gw is not None and gb is not None and gw.is_contiguous() and gb.is_contiguous()
+    if direct:                                   # the kernel ACCUMULATES (atomics): straight into the existing .grad
+        dgamma, dbeta = gw, gb
+    else:
+        dgamma, dbeta = arena.take((D,)), arena.take((D,))
     if GradStore._key(x) in produced:
         gx, fresh = store.target(x)
     else:
         gx, fresh = torch.empty_like(x), True
     ops.layernorm_bwd(x, norm.weight.detach(), stats, g, gx, not fresh, dgamma, dbeta)
-    _acc_param(norm.weight, dgamma, shared=True)
-    _acc_param(norm.bias, dbeta, shared=True)
+    if not direct:
+        _acc_param(norm.weight, dgamma, shared=True)
+        _acc_param(norm.bias, dbeta, shared=True)
 
 
 def _embed_bwd(e, store, mi):

@@ -57,6 +57,32 @@ def main():
         print(f"K={K:4d} N={Nout:4d} res={int(res)} act={act}: {us:8.1f} us  {2.0 * M * K * Nout / us * 1e-6:6.1f} TFLOP/s  "
               f"{by / us * 1e-6:6.2f} TB/s  max err {err:.1e}", flush=True)
     print(f"sum {tot:.0f} us")
+    # weight gradients dW = dZ^T X of the same layers (mmb_grad_weight_rows, 8 accumulator replicas as the reverse pass)
+    R = 8
+    for gpath in ("f32", "x6"):
+        os.environ["MMB_GW_PATH"] = gpath
+        tot = 0.0
+        for K, Nout, res, act in SHAPES:
+            if only and only != f"{K},{Nout}":
+                continue
+            x = torch.randn(M, K, generator=g).cuda()
+            dz = torch.randn(M, Nout, generator=g).cuda()
+            dwr = torch.zeros(R, Nout * K, device="cuda")
+            dbr = torch.zeros(R, Nout, device="cuda")
+            fn = lambda: ops.grad_weight_rows(x, dz, dwr[0].view(Nout, K), dbr[0], replicas=R, rep_stride=dwr.stride(0),
+                                              db_stride=dbr.stride(0))
+            fn()
+            ref = dz[:20000].double().t() @ x[:20000].double()
+            dwr.zero_(); dbr.zero_()
+            ops.grad_weight_rows(x[:20000], dz[:20000], dwr[0].view(Nout, K), dbr[0], replicas=R, rep_stride=dwr.stride(0),
+                                 db_stride=dbr.stride(0))
+            got = dwr.sum(0).view(Nout, K).double()
+            err = float((got - ref).abs().max() / ref.abs().max())
+            us = timed(fn)
+            tot += us
+            print(f"gradw[{gpath}] K={K:4d} N={Nout:4d}: {us:8.1f} us  {2.0 * M * K * Nout / us * 1e-6:6.1f} TFLOP/s  "
+                  f"{4.0 * M * (K + Nout) / us * 1e-6:5.2f} TB/s  rel err {err:.1e}", flush=True)
+        print(f"gradw[{gpath}] sum {tot:.0f} us")
 
 
 if __name__ == "__main__":

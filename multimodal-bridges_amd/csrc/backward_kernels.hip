@@ -241,7 +241,35 @@ grad_weight_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restr
 // the stream (a wave only reads what it wrote).  The four waves' partial tiles are summed through
 // LDS and leave as one atomicAdd per element and block; db is the column sum of the A values.
 // Requires K and Nout to be multiples of 4 and 16-byte aligned rows (ragged last windows are zero-filled).
-template <int OT, int KT>
+// exact three-plane bf16 split of 8 floats (fused_common.h: split8): hi + mid + lo = the fp32 value
+typedef __bf16 gw_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t gw_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t gw_pk(float a, float b) {
+  const gw_bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ void gw_split8(const float (&v)[8], gw_bf16x8& h, gw_bf16x8& m, gw_bf16x8& l) {
+  uint32_t ph[4], pm[4], pq[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = v[2 * j], b = v[2 * j + 1];
+    ph[j] = gw_pk(a, b);
+    const float ra = a - __builtin_bit_cast(float, ph[j] << 16), rb = b - __builtin_bit_cast(float, ph[j] & 0xFFFF0000u);
+    pm[j] = gw_pk(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, pm[j] << 16), sb = rb - __builtin_bit_cast(float, pm[j] & 0xFFFF0000u);
+    pq[j] = gw_pk(sa, sb);
+  }
+  const gw_u32x4 H = {ph[0], ph[1], ph[2], ph[3]}, M = {pm[0], pm[1], pm[2], pm[3]}, L = {pq[0], pq[1], pq[2], pq[3]};
+  h = __builtin_bit_cast(gw_bf16x8, H);
+  m = __builtin_bit_cast(gw_bf16x8, M);
+  l = __builtin_bit_cast(gw_bf16x8, L);
+}
+
+// X6: the 16 rows of a chunk are ONE k-extent of v_mfma_f32_32x32x16_bf16 (lane half h takes rows 8h..8h+7 of its
+// column); both operands are split in registers into three exact bf16 planes and every fp32 product is six plane
+// products (small terms first) -- 6 x 32 cycles per tile and chunk instead of 8 x 64 on the fp32 MFMA.
+template <int OT, int KT, bool X6>
 __device__ __forceinline__ void
 grad_weight_rows_body(int M, const float* __restrict__ X, int64_t x_ld, int K, const float* __restrict__ dZ,
                       int64_t dz_ld, int Nout, float* __restrict__ dW, int64_t dw_ld, float* __restrict__ db,
@@ -305,6 +333,28 @@ grad_weight_rows_body(int M, const float* __restrict__ X, int64_t x_ld, int K, c
   for (; row0 < r_end; row0 += stride) {
     park_chunk(row0);                                   // (waits for the loads of this chunk)
     if (row0 + stride < r_end) load_chunk(row0 + stride);
+    if constexpr (X6) {
+      gw_bf16x8 ah[OT], am[OT], al[OT];
+      sfor<OT>([&](auto c) { constexpr int t = decltype(c)::v;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = zs[(8 * half + j) * ZP + 32 * t + i32];
+        dbs[t] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        gw_split8(v, ah[t], am[t], al[t]); });
+      sfor<KT>([&](auto kc) { constexpr int kt = decltype(kc)::v;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = xs[(8 * half + j) * XP + 32 * kt + i32];
+        gw_bf16x8 bh, bm, bl;
+        gw_split8(v, bh, bm, bl);
+        sfor<OT>([&](auto oc) { constexpr int ot = decltype(oc)::v;
+          acc[ot][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ot], bh, acc[ot][kt], 0, 0, 0);
+          acc[ot][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[ot], bm, acc[ot][kt], 0, 0, 0);
+          acc[ot][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ot], bl, acc[ot][kt], 0, 0, 0);
+          acc[ot][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[ot], bh, acc[ot][kt], 0, 0, 0);
+          acc[ot][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ot], bm, acc[ot][kt], 0, 0, 0);
+          acc[ot][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ot], bh, acc[ot][kt], 0, 0, 0); }); });
+    } else {
 #pragma unroll
     for (int p = 0; p < R / 2; ++p) {
       float a[OT], b[KT];
@@ -314,6 +364,7 @@ grad_weight_rows_body(int M, const float* __restrict__ X, int64_t x_ld, int K, c
         dbs[ot] += a[ot];
         sfor<KT>([&](auto kc) { constexpr int kt = decltype(kc)::v;
           acc[ot][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ot], b[kt], acc[ot][kt], 0, 0, 0); }); });
+    }
     }
   }
 
@@ -358,13 +409,21 @@ grad_weight_rows_body(int M, const float* __restrict__ X, int64_t x_ld, int K, c
   }
 }
 
-template <int OT, int KT>
+template <int OT, int KT, bool X6>
 __global__ void __launch_bounds__(256)
 grad_weight_rows_kernel(int M, const float* __restrict__ X, int64_t x_ld, int K, const float* __restrict__ dZ,
                         int64_t dz_ld, int Nout, float* __restrict__ dW, int64_t dw_ld, float* __restrict__ db,
-                        int rows_per_block, int replicas, int64_t rep_stride, int64_t db_stride) {
-  grad_weight_rows_body<OT, KT>(M, X, x_ld, K, dZ, dz_ld, Nout, dW, dw_ld, db, rows_per_block, replicas, rep_stride,
-                                db_stride, blockIdx.x, blockIdx.y, blockIdx.z);
+                        int rows_per_block, int replicas, int64_t rep_stride, int64_t db_stride, int nbx, int nwin,
+                        int nby) {
+  // 1-D grid, XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2); the
+  // nwin = nby * nbz workgroups that stream the SAME rows (one per K window x output window) get ids 8 apart -- same
+  // XCD, dispatched together -- so the rows come from HBM once instead of once per window (128 -> 384 at OT x KT =
+  // 4 x 2: 708 MB of re-reads against 315 MB)
+  const int g = blockIdx.x, slot = g >> 3;
+  const int win = slot % nwin, bx = (slot / nwin) * 8 + (g & 7);
+  if (bx >= nbx) return;
+  grad_weight_rows_body<OT, KT, X6>(M, X, x_ld, K, dZ, dz_ld, Nout, dW, dw_ld, db, rows_per_block, replicas, rep_stride,
+                                db_stride, bx, win % nby, win / nby);
 }
 
 // Many independent weight-gradient problems of one tile class in ONE launch (a training step has ~100 of
@@ -381,7 +440,7 @@ struct GwProb {            // all fields 8 bytes: built on the host as an int64 
   int64_t block_begin, block_end;
 };
 
-template <int OT, int KT>
+template <int OT, int KT, bool X6>
 __global__ void __launch_bounds__(256)
 grad_weight_rows_multi_kernel(const GwProb* __restrict__ probs, int n_probs) {
   const int64_t id = blockIdx.x;
@@ -407,7 +466,7 @@ grad_weight_rows_multi_kernel(const GwProb* __restrict__ probs, int n_probs) {
     by = rest % nby;
     bz = rest / nby;
   }
-  grad_weight_rows_body<OT, KT>((int)q.M, q.X, q.x_ld, (int)q.K, q.dZ, q.dz_ld, (int)q.Nout, q.dW, q.dw_ld, q.db,
+  grad_weight_rows_body<OT, KT, X6>((int)q.M, q.X, q.x_ld, (int)q.K, q.dZ, q.dz_ld, (int)q.Nout, q.dW, q.dw_ld, q.db,
                                 (int)q.rpb, (int)q.replicas, q.rep_stride, q.db_stride, bx, by, bz);
 }
 
@@ -444,6 +503,13 @@ grad_weight_smallk_kernel(int M, const float* __restrict__ X, int64_t x_ld, int 
   }
 }
 
+// weight-gradient arithmetic (A/B switch for tests and profiles): MMB_GW_PATH = f32 (fp32 MFMA) | x6 (default: six
+// bf16-plane products per fp32 product)
+static bool gw_x6() {
+  const char* e = getenv("MMB_GW_PATH");
+  return !(e && e[0] == 'f');
+}
+
 }  // namespace mmb
 
 using namespace mmb;
@@ -471,7 +537,12 @@ extern "C" int mmb_grad_weight_rows_multi(int OTb, int KTb, const void* probs, i
   MMB_REQUIRE(probs && n_probs > 0 && total_blocks > 0, "mmb_grad_weight_rows_multi: empty table");
   const GwProb* P = reinterpret_cast<const GwProb*>(probs);
   hipStream_t st = as_stream(stream);
-#define GWM(O_, K_) hipLaunchKernelGGL((grad_weight_rows_multi_kernel<O_, K_>), dim3(total_blocks), dim3(256), 0, st, P, n_probs)
+  const bool x6 = gw_x6();
+#define GWM(O_, K_)                                                                                                    \
+  do {                                                                                                                 \
+    if (x6) hipLaunchKernelGGL((grad_weight_rows_multi_kernel<O_, K_, true>), dim3(total_blocks), dim3(256), 0, st, P, n_probs); \
+    else hipLaunchKernelGGL((grad_weight_rows_multi_kernel<O_, K_, false>), dim3(total_blocks), dim3(256), 0, st, P, n_probs);   \
+  } while (0)
   if (OTb == 1 && KTb == 1) GWM(1, 1);
   else if (OTb == 1 && KTb == 2) GWM(1, 2);
   else if (OTb == 1 && KTb == 4) GWM(1, 4);
@@ -502,13 +573,26 @@ extern "C" int mmb_grad_weight_rows(int M, const float* X, int64_t x_ld, int K, 
   const int ot_all = (Nout + 31) / 32, kt_all = (K + 31) / 32;
   int OTb = ot_all >= 4 ? 4 : (ot_all >= 2 ? 2 : 1);
   int KTb = kt_all >= 4 ? 4 : (kt_all >= 2 ? 2 : 1);
-  while (OTb * KTb > 8) { if (KTb >= OTb) KTb /= 2; else OTb /= 2; }
-  int rpb = 512;                                         // 8 chunks per wave
+  // tiles per block: 8 keep each row on chip longest but leave one wave per SIMD (182 registers), and the stream is
+  // latency-bound (one 16-row chunk in flight per wave); 4 tiles run 3-4 waves per SIMD -- the extra windows re-read
+  // the rows from L2, not HBM (XCD-aware order).  Sweep on the S4 shapes: 1362 / 953 / 1037 us at 8 / 4 / 2 tiles.
+  int max_tiles = M >= 65536 ? 4 : 8;
+  if (const char* e = getenv("MMB_GW_TILES")) max_tiles = atoi(e) > 0 ? atoi(e) : max_tiles;      // tuning knob
+  while (OTb * KTb > max_tiles) { if (KTb >= OTb) KTb /= 2; else OTb /= 2; }
+  int rpb = M >= 65536 ? 1024 : 512;                     // 16 / 8 chunks per wave
   if (M <= 16384) rpb = 64;
   if (const char* e = getenv("MMB_GW_RPB")) rpb = atoi(e) > 0 ? atoi(e) : rpb;      // tuning knob
-  dim3 grid((M + rpb - 1) / rpb, (kt_all + KTb - 1) / KTb, (ot_all + OTb - 1) / OTb);
+  const int nbx = (M + rpb - 1) / rpb, nby = (kt_all + KTb - 1) / KTb, nbz = (ot_all + OTb - 1) / OTb;
+  const int nwin = nby * nbz;
+  MMB_REQUIRE((int64_t)((nbx + 7) / 8) * 8 * nwin < (1ll << 31), "mmb_grad_weight_rows: too many blocks");
+  dim3 grid((nbx + 7) / 8 * 8 * nwin);
   hipStream_t st = as_stream(stream);
-#define GWR(O_, K_) hipLaunchKernelGGL((grad_weight_rows_kernel<O_, K_>), grid, dim3(256), 0, st, M, X, x_ld, K, dZ, dz_ld, Nout, dW, dw_ld, db, rpb, replicas, rep_stride, db_stride)
+  const bool x6 = gw_x6();
+#define GWR(O_, K_)                                                                                                    \
+  do {                                                                                                                 \
+    if (x6) hipLaunchKernelGGL((grad_weight_rows_kernel<O_, K_, true>), grid, dim3(256), 0, st, M, X, x_ld, K, dZ, dz_ld, Nout, dW, dw_ld, db, rpb, replicas, rep_stride, db_stride, nbx, nwin, nby); \
+    else hipLaunchKernelGGL((grad_weight_rows_kernel<O_, K_, false>), grid, dim3(256), 0, st, M, X, x_ld, K, dZ, dz_ld, Nout, dW, dw_ld, db, rpb, replicas, rep_stride, db_stride, nbx, nwin, nby);   \
+  } while (0)
   if (OTb == 1 && KTb == 1) GWR(1, 1);
   else if (OTb == 1 && KTb == 2) GWR(1, 2);
   else if (OTb == 1 && KTb == 4) GWR(1, 4);

@@ -421,7 +421,8 @@ def gw_class(K, Nout):
     ot_all, kt_all = (Nout + 31) // 32, (K + 31) // 32
     OTb = 4 if ot_all >= 4 else (2 if ot_all >= 2 else 1)
     KTb = 4 if kt_all >= 4 else (2 if kt_all >= 2 else 1)
-    while OTb * KTb > 8:
+    max_tiles = int(os.environ.get("MMB_GW_TILES_MULTI", "4"))       # 8 tiles leave one wave per SIMD: S2 +11 %, S3 unchanged
+    while OTb * KTb > max_tiles:
         if KTb >= OTb:
             KTb //= 2
         else:

@@ -306,33 +306,35 @@ grad_weight_rows_body(int M, const float* __restrict__ X, int64_t x_ld, int K, c
   sfor<XF4>([&](auto c) { constexpr int i = decltype(c)::v; const int f = i * 64 + lane; xr[i] = f / (KW / 4); xc[i] = 4 * (f % (KW / 4)); });
   sfor<ZF4>([&](auto c) { constexpr int i = decltype(c)::v; const int f = i * 64 + lane; zr[i] = f / (OW / 4); zc[i] = 4 * (f % (OW / 4)); });
 
-  float4 xn[XF4], zn[ZF4];
-  auto load_chunk = [&](int row0) {                      // rows past the end are clamped here, zeroed at the park
-    sfor<XF4>([&](auto c) { constexpr int i = decltype(c)::v;
-      const int64_t rr = min(row0 + xr[i], r_end - 1);
-      xn[i] = make_float4(0.f, 0.f, 0.f, 0.f);                 // columns past K (ragged last window) stay zero
-      if (k0 + xc[i] < K) xn[i] = *reinterpret_cast<const float4*>(X + rr * x_ld + k0 + xc[i]); });
+  // two chunks in flight per wave (buffers A, B): the stream is latency-bound with one.  Loads are unconditional
+  // (rows past the end are clamped here and zeroed at the park), so their number in flight is static and the park of
+  // the older buffer waits for that buffer only.
+  float4 xa[XF4], za[ZF4], xb[XF4], zb[ZF4];
+  auto load_chunk = [&](int row0, float4 (&xn)[XF4], float4 (&zn)[ZF4]) __attribute__((always_inline)) {
+    sfor<XF4>([&](auto c) { constexpr int i = decltype(c)::v;          // (no branch: rows AND columns clamped into
+      const int64_t rr = min(row0 + xr[i], r_end - 1);                 //  valid memory, zeroed at the park)
+      xn[i] = *reinterpret_cast<const float4*>(X + rr * x_ld + min(k0 + xc[i], K - 4)); });
     sfor<ZF4>([&](auto c) { constexpr int i = decltype(c)::v;
       const int64_t rr = min(row0 + zr[i], r_end - 1);
-      zn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (o0 + zc[i] < Nout) zn[i] = *reinterpret_cast<const float4*>(dZ + rr * dz_ld + o0 + zc[i]); });
+      zn[i] = *reinterpret_cast<const float4*>(dZ + rr * dz_ld + min(o0 + zc[i], Nout - 4)); });
   };
-  auto park_chunk = [&](int row0) {
+  auto park_chunk = [&](int row0, const float4 (&xn)[XF4], const float4 (&zn)[ZF4]) __attribute__((always_inline)) {
     sfor<XF4>([&](auto c) { constexpr int i = decltype(c)::v;
-      *reinterpret_cast<float4*>(xs + xr[i] * XP + xc[i]) = xn[i]; });
+      float4 v = xn[i];
+      if (k0 + xc[i] >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);        // columns past K (ragged last window)
+      *reinterpret_cast<float4*>(xs + xr[i] * XP + xc[i]) = v; });
     sfor<ZF4>([&](auto c) { constexpr int i = decltype(c)::v;
       float4 v = zn[i];
-      if (row0 + zr[i] >= r_end) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + zr[i] >= r_end || o0 + zc[i] >= Nout) v = make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<float4*>(zs + zr[i] * ZP + zc[i]) = v; });
   };
 
   // wave w owns chunks w, w+4, ... of the block
   const int stride = 4 * R;
   int row0 = r_begin + wave * R;
-  if (row0 < r_end) load_chunk(row0);
-  for (; row0 < r_end; row0 += stride) {
-    park_chunk(row0);                                   // (waits for the loads of this chunk)
-    if (row0 + stride < r_end) load_chunk(row0 + stride);
+  load_chunk(row0, xa, za);
+  if (rows_per_block % (2 * stride) == 0) load_chunk(row0 + stride, xb, zb);
+  auto mma_chunk = [&]() __attribute__((always_inline)) {
     if constexpr (X6) {
       gw_bf16x8 ah[OT], am[OT], al[OT];
       sfor<OT>([&](auto c) { constexpr int t = decltype(c)::v;
@@ -365,6 +367,24 @@ grad_weight_rows_body(int M, const float* __restrict__ X, int64_t x_ld, int K, c
         sfor<KT>([&](auto kc) { constexpr int kt = decltype(kc)::v;
           acc[ot][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ot], b[kt], acc[ot][kt], 0, 0, 0); }); });
     }
+    }
+  };
+  if (rows_per_block % (2 * stride) == 0) {
+    // every wave owns an EVEN number of chunks (the last block's may lie past the end: clamped loads, zeroed dZ),
+    // so both halves run unconditionally and the waits stay static
+    for (; row0 < r_end; row0 += 2 * stride) {
+      park_chunk(row0, xa, za);                         // (waits for buffer A only)
+      load_chunk(row0 + 2 * stride, xa, za);
+      mma_chunk();
+      park_chunk(row0 + stride, xb, zb);
+      load_chunk(row0 + 3 * stride, xb, zb);
+      mma_chunk();
+    }
+  } else {                                              // short blocks (per-jet problems): one buffer
+    for (; row0 < r_end; row0 += stride) {
+      park_chunk(row0, xa, za);
+      load_chunk(row0 + stride, xa, za);
+      mma_chunk();
     }
   }
 

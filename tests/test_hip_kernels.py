@@ -376,7 +376,8 @@ def test_grad_weight_rows_multi(ops):
     mixed row counts (per-particle and per-jet), replicas, strided operands, column slices of wider gradients."""
     g = torch.Generator().manual_seed(77)
     shapes = [(20000, 64, 64, 8), (1000, 64, 64, 1), (20000, 128, 128, 8), (513, 32, 64, 1), (20000, 64, 128, 8),
-              (700, 144, 64, 1), (20000, 16, 64, 8), (333, 64, 16, 1), (900, 256, 128, 1)]
+              (700, 144, 64, 1), (20000, 16, 64, 8), (333, 64, 16, 1), (900, 256, 128, 1), (20000, 128, 32, 8),
+              (20000, 32, 128, 8)]
     probs, keep = {}, []
     for M, K, Nout, R in shapes:
         Xw = torch.randn(M, K + 4, generator=g).cuda()

@@ -130,7 +130,8 @@ def cpu_baseline(model, config, workload, n_jets, n_steps):
             "thermostat_fn": m.thermostat_fn, "solver_continuous": m.solver_continuous,
             "bridge_continuous": getattr(m, "bridge_continuous", None),
             "solver_discrete": m.solver_discrete, "vocab_size": config.data.vocab_size,
-            "encoder_name": config.encoder.name, "skip_connection": config.encoder.skip_connection}
+            "encoder_name": config.encoder.name, "skip_connection": getattr(config.encoder, "skip_connection", True),
+            "num_heads": getattr(config.encoder, "num_heads", None)}
     N = config.data.max_num_particles
     pmf = load_pmf(os.path.join(ROOT, "tests", "golden"))
     threads = torch.get_num_threads()

@@ -333,6 +333,20 @@ def main():
                     "algorithmic_flops_per_particle_per_forward": fpp, "forwards_per_launch": n_fwd,
                     "launches": fz["n"], "avg_launch_us": fz["ms"] * 1e3 / fz["n"],
                     "share_of_gpu_time": fz["ms"] / total_ms}
+        elif groups.get("mmb_toy_generate"):
+            tz = groups["mmb_toy_generate"]
+            enc = model.encoder
+            H, Dc, V = enc.dim_hidden, enc.dim, enc.vocab_size
+            fpp = 2.0 * ((1 + Dc + H // 4) * H + 3 * H * H + H * (Dc + V))        # per point and forward
+            alg = fpp * config.data.max_num_particles * B * 2 * args.solver_steps * tz["n"]
+            achieved = alg / (tz["ms"] * 1e-3) / 1e12
+            roof = {"kernel": "toy_generate_kernel (whole generation loop of the toy MLP; v_mfma_f32_32x32x2_f32, "
+                              "32 points per wave)", "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                    "note": f"{(B * config.data.max_num_particles + 31) // 32} waves of work on a 1024-SIMD chip: the "
+                            "configured batch is latency-bound; --batch 32768 fills the chip",
+                    "launches": tz["n"], "avg_launch_us": tz["ms"] * 1e3 / tz["n"],
+                    "share_of_gpu_time": tz["ms"] / total_ms}
         elif dom:
             achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             # the per-particle layers run linear_stream_x6_kernel: every fp32 product as six bf16 MFMA products

@@ -382,6 +382,19 @@ int mmb_layernorm_bwd(int64_t M, int D, const float* x, int64_t x_ld, const floa
 int mmb_sum_replicas(int64_t n, int replicas, int64_t stride, const float* src, float* dst, int accumulate,
                      void* stream);
 
+/* The whole generation loop of the toy hybrid experiment in ONE launch: MultiModalMLP (notebooks/data_toys.ipynb
+ * cell 3: embed -> 4 Linear with SELU -> two heads) inside simulate_dynamics (multimodal_bridge_matching.py:227-259;
+ * Euler / Euler-Maruyama drift steps interleaved with tau-leap jumps, final state = argmax of the last rates), as
+ * mmb_fused_epic_generate does for the EPiC model.  Compiled for dim_hidden H = 64, Dc = 2, V = 8 (the notebook's and
+ * configs/S1_toy.yaml's); other widths run the layered entry points.  weights: 12 device pointers
+ * {body.0.weight (H,1+Dc+H/4), body.0.bias, body.2.*, body.4.*, body.6.*, continous_head.weight (Dc,H), .bias,
+ * discrete_head.weight (V,H), .bias}; table = embed.weight (V,H/4).  x (B*N,Dc), k (B*N) are updated in place where
+ * maskf != 0.  delta_n (steps,B,N,V) / delta_w (steps,B,N,Dc): injected noise or NULL -> Philox(seed, offset + step). */
+int mmb_toy_generate(int B, int N, int H, int Dc, int V, const float* table, const float* const* weights,
+                     const float* maskf, float* x, int64_t* k, int steps, const float* times, float dt,
+                     int thermo_kind, float gamma, const float* delta_n, uint64_t seed, uint64_t offset, int em,
+                     float em_sigma, const float* delta_w, void* stream);
+
 /* ---------------------------------------------------------------- K-E fused (generation) */
 /* Whole MultiModalEPiC forward (multimodal_epic.py:158-194 incl. embedder.py:74-80) for one jet
  * per workgroup with activations resident in registers; `packed`/`desc` come from

@@ -931,6 +931,193 @@ extern "C" int mmb_fused_uni_generate(int variant, int B, int N, const float* pa
   return check_launch("mmb_fused_uni_generate");
 }
 
+// ==================================================================== MultiModalMLP (toy, S1) ====
+// The whole generation loop of the toy hybrid experiment (notebooks/data_toys.ipynb cell 3 inside
+// multimodal_bridge_matching.py:227-259) in ONE launch: the layered path needs 16 launches per grid point and is
+// launch-bound (25 ms per 100-step generation of 1024 points).  One wave owns 32 points (lane & 31 = point, both lane
+// halves carry its state); all weights (57 KB fp32) sit in LDS; activations stay in registers as TRANSPOSED tiles in
+// the C/D layout of v_mfma_f32_32x32x2_f32 (lane = point, registers = features), so a layer's output IS the next
+// layer's B operand: MFMA step r contracts the two features that register r holds in the two lane halves and the A
+// operand is those two columns of the weight matrix (exact fp32: bit-for-bit an fmaf chain).
+struct ToyW {
+  const float* table;                      // (V, H/4) embedding
+  const float *w0, *b0, *w1, *b1, *w2, *b2, *w3, *b3;   // body: (H, 1+DC+H/4), 3 x (H, H)
+  const float *wc, *bc, *wd, *bd;          // heads: (DC, H), (V, H)
+};
+
+__device__ __forceinline__ float selu_f(float x) {
+  return x > 0.0f ? 1.0507009873554804934193349852946f * x
+                  : (1.0507009873554804934193349852946f * 1.6732632423543772848170429916717f) * (expf(x) - 1.0f);
+}
+__device__ __forceinline__ int toy_crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+template <int H, int DC>
+__global__ void __launch_bounds__(256)
+toy_generate_kernel(ToyW W, GenArgs Gn, int B, int N, const float* __restrict__ maskf, float* __restrict__ x,
+                    int64_t* __restrict__ k) {
+  constexpr int V = 8, E = H / 4, K0 = 1 + DC + E, HT = H / 32;
+  constexpr int P0 = 33, PH = H + 1;                       // LDS pitches (odd: conflict-free column reads)
+  static_assert(K0 <= 32 && DC + V <= 32 && H % 32 == 0, "toy kernel shape");
+  extern __shared__ float sm[];
+  float* w0 = sm;                          // [H][P0]   columns >= K0 are zeros
+  float* wl = w0 + H * P0;                 // [3][H][PH]
+  float* wh = wl + 3 * H * PH;             // [32][PH]  rows 0..DC-1 drift head, DC..DC+V-1 logits, rest zeros
+  float* bs = wh + 32 * PH;                // [4][H] + [32]
+  float* tb = bs + 4 * H + 32;             // [V][E]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < H * P0; i += blockDim.x) {
+    const int o = i / P0, c = i - o * P0;
+    w0[i] = c < K0 ? W.w0[o * K0 + c] : 0.0f;
+  }
+  for (int i = tid; i < 3 * H * PH; i += blockDim.x) {
+    const int l = i / (H * PH), r = i - l * (H * PH), o = r / PH, c = r - o * PH;
+    const float* src = l == 0 ? W.w1 : (l == 1 ? W.w2 : W.w3);
+    wl[i] = c < H ? src[o * H + c] : 0.0f;
+  }
+  for (int i = tid; i < 32 * PH; i += blockDim.x) {
+    const int o = i / PH, c = i - o * PH;
+    float v = 0.0f;
+    if (c < H) v = o < DC ? W.wc[o * H + c] : (o < DC + V ? W.wd[(o - DC) * H + c] : 0.0f);
+    wh[i] = v;
+  }
+  for (int i = tid; i < 4 * H + 32; i += blockDim.x) {
+    float v = 0.0f;
+    if (i < H) v = W.b0[i];
+    else if (i < 2 * H) v = W.b1[i - H];
+    else if (i < 3 * H) v = W.b2[i - 2 * H];
+    else if (i < 4 * H) v = W.b3[i - 3 * H];
+    else { const int o = i - 4 * H; v = o < DC ? W.bc[o] : (o < DC + V ? W.bd[o - DC] : 0.0f); }
+    bs[i] = v;
+  }
+  for (int i = tid; i < V * E; i += blockDim.x) tb[i] = W.table[i];
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6, col = lane & 31, half = lane >> 5;
+  const int64_t P = (int64_t)B * N;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile * 32 < P; tile += (int64_t)gridDim.x * 4) {
+    const int64_t gp = tile * 32 + col;
+    const bool inb = gp < P;
+    const int64_t gl = inb ? gp : P - 1;
+    const bool valid = inb && maskf[gl] != 0.0f;
+    const int b = (int)(gl / N), p = (int)(gl - (int64_t)b * N);
+    float xp[DC];
+#pragma unroll
+    for (int d = 0; d < DC; ++d) xp[d] = x[gl * DC + d];
+    int kp = (int)k[gl];
+
+    // heads of one forward pass at time tt: out[r] = row toy_crow(r, half) of [drift | logits | 0...]
+    auto forward = [&](float tt, f32x16& out) __attribute__((always_inline)) {
+      f32x16 in;
+      ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v;
+        const int f = toy_crow(r, half);
+        float v = 0.0f;
+        if (f == 0) v = tt;
+        else if (f > DC && f < K0) v = tb[kp * E + (f - 1 - DC)];
+        ffor<DC>([&](auto dc) { constexpr int d = decltype(dc)::v; if (f == 1 + d) v = xp[d]; });
+        in[r] = v; });
+      f32x16 h[HT], g[HT];
+      ffor<HT>([&](auto mc) { constexpr int mt = decltype(mc)::v;
+        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; h[mt][r] = bs[32 * mt + toy_crow(r, half)]; });
+        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v;
+          h[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[(32 * mt + col) * P0 + toy_crow(r, half)], in[r], h[mt], 0, 0, 0); });
+        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; h[mt][r] = selu_f(h[mt][r]); }); });
+      ffor<3>([&](auto lc) { constexpr int l = decltype(lc)::v;
+        const float* wm = wl + l * H * PH;
+        ffor<HT>([&](auto mc) { constexpr int mt = decltype(mc)::v;
+          ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; g[mt][r] = bs[(l + 1) * H + 32 * mt + toy_crow(r, half)]; });
+          ffor<HT>([&](auto kc) { constexpr int kt = decltype(kc)::v;
+            ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v;
+              g[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wm[(32 * mt + col) * PH + 32 * kt + toy_crow(r, half)], h[kt][r],
+                                                          g[mt], 0, 0, 0); }); }); });
+        ffor<HT>([&](auto mc) { constexpr int mt = decltype(mc)::v;
+          ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; h[mt][r] = l < 2 ? selu_f(g[mt][r]) : g[mt][r]; }); }); });
+      ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; out[r] = bs[4 * H + toy_crow(r, half)]; });
+      ffor<HT>([&](auto kc) { constexpr int kt = decltype(kc)::v;
+        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v;
+          out = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[col * PH + 32 * kt + toy_crow(r, half)], h[kt][r], out, 0, 0, 0); }); });
+    };
+    // row `row` (compile time) of the head tile, delivered to BOTH lane halves
+    auto head_row = [&](const f32x16& out, auto rowc) __attribute__((always_inline)) {
+      constexpr int row = decltype(rowc)::v;
+      constexpr int hsrc = (row >> 2) & 1, reg = (row & 3) + 4 * (row >> 3);
+      const float mine = out[reg], other = __shfl_xor(mine, 32, 64);
+      return half == hsrc ? mine : other;
+    };
+
+    for (int s = 0; s < Gn.steps; ++s) {
+      const float tt = Gn.times[s];
+      f32x16 out;
+      forward(tt, out);
+      {
+        float w[DC];
+#pragma unroll
+        for (int d = 0; d < DC; ++d) w[d] = 0.0f;
+        float sig = 0.0f;
+        if (Gn.em) {
+          sig = Gn.em_sigma * sqrtf(tt * (1.0f - tt));
+          if (Gn.delta_w != nullptr) {
+            if (valid) {
+              const float* dw = Gn.delta_w + (((int64_t)s * B + b) * N + p) * DC;
+#pragma unroll
+              for (int d = 0; d < DC; ++d) w[d] = dw[d];
+            }
+          } else {
+            uint32_t q[4];
+            philox4(Gn.seed, Gn.offset + (uint64_t)s, (uint64_t)gl, 0xE001u, q);
+            const float r0 = sqrtf(-2.0f * __logf(u01_open0(q[0]))), r1 = sqrtf(-2.0f * __logf(u01_open0(q[2])));
+            const float z[4] = {r0 * __builtin_amdgcn_cosf(u01(q[1])), r0 * __builtin_amdgcn_sinf(u01(q[1])),
+                                r1 * __builtin_amdgcn_cosf(u01(q[3])), r1 * __builtin_amdgcn_sinf(u01(q[3]))};
+#pragma unroll
+            for (int d = 0; d < DC; ++d) w[d] = z[d & 3];
+          }
+        }
+        ffor<DC>([&](auto dc) { constexpr int d = decltype(dc)::v;
+          const float drift = head_row(out, IF<d>{});
+          xp[d] += Gn.em ? (Gn.dt * drift + sig * w[d]) : Gn.dt * drift; });
+      }
+      // tau-leap on the logits head, which sees the UPDATED x at the same t (solvers.py:59-81)
+      forward(tt, out);
+      float r[V];
+      ffor<V>([&](auto vc) { constexpr int v = decltype(vc)::v; r[v] = head_row(out, IF<DC + v>{}); });
+      kp = jump_step(r, kp, tt, Gn, s == Gn.steps - 1, valid, B, N, b, p, s, gl);
+    }
+    if (valid && half == 0) {
+#pragma unroll
+      for (int d = 0; d < DC; ++d) x[gp * DC + d] = xp[d];
+      k[gp] = kp;
+    }
+  }
+}
+
+extern "C" int mmb_toy_generate(int B, int N, int H, int Dc, int V, const float* table, const float* const* weights,
+                                const float* maskf, float* x, int64_t* k, int steps, const float* times, float dt,
+                                int thermo_kind, float gamma, const float* delta_n, uint64_t seed, uint64_t offset,
+                                int em, float em_sigma, const float* delta_w, void* stream) {
+  MMB_REQUIRE(B > 0 && N > 0 && steps > 0, "mmb_toy_generate: empty shape");
+  MMB_REQUIRE(H == 64 && Dc == 2 && V == 8, "mmb_toy_generate: compiled for dim_hidden 64, 2 continuous features, "
+              "8 tokens (got %d, %d, %d): use the layered entry points", H, Dc, V);
+  MMB_REQUIRE(table && weights && maskf && x && k && times, "mmb_toy_generate: NULL argument");
+  for (int i = 0; i < 12; ++i) MMB_REQUIRE(weights[i], "mmb_toy_generate: NULL weight %d", i);
+  MMB_REQUIRE(thermo_kind >= 0 && thermo_kind <= 4, "mmb_toy_generate: bad thermostat");
+  ToyW W{table, weights[0], weights[1], weights[2], weights[3], weights[4], weights[5], weights[6], weights[7],
+         weights[8], weights[9], weights[10], weights[11]};
+  GenArgs Gn{steps, times, nullptr, nullptr, 0, dt, thermo_kind, (float)(-(double)V * (double)gamma), delta_n, seed, offset,
+             em, em_sigma, delta_w};
+  constexpr int HH = 64;
+  const size_t lds = (size_t)(HH * 33 + 3 * HH * (HH + 1) + 32 * (HH + 1) + 4 * HH + 32 + 8 * (HH / 4)) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    MMB_REQUIRE(hipFuncSetAttribute((const void*)toy_generate_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) == hipSuccess, "mmb_toy_generate: cannot raise the dynamic LDS limit");
+    attr_set = true;
+  }
+  const int64_t tiles = ((int64_t)B * N + 31) / 32;
+  const int64_t blocks = (tiles + 3) / 4;
+  hipLaunchKernelGGL((toy_generate_kernel<64, 2>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), lds,
+                     as_stream(stream), W, Gn, B, N, maskf, x, k);
+  return check_launch("mmb_toy_generate");
+}
+
 #ifdef MMB_FE_PROF
 extern "C" int mmb_debug_fused_prof(unsigned long long* out16, int reset) {
   if (reset) {

@@ -109,6 +109,9 @@ SIGNATURES = {
     "mmb_toy_embedding_bwd": [C.c_int64, C.c_int, C.c_int, c_i64p, c_f32p, C.c_int64, C.c_int, c_f32p, c_stream],
     "mmb_toy_sample": [C.c_int, C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_uint64, c_f32p, c_i64p, c_stream],
     "mmb_aoj_features": [C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_i64p, c_i64p, c_stream],
+    "mmb_toy_generate": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.POINTER(C.c_void_p), c_f32p, c_f32p,
+                         c_i64p, C.c_int, c_f32p, C.c_float, C.c_int, C.c_float, c_f32p, C.c_uint64, C.c_uint64, C.c_int,
+                         C.c_float, c_f32p, c_stream],
     "mmb_grad_weight": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
                         C.POINTER(C.c_int), c_f32p, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p, c_stream],
 }

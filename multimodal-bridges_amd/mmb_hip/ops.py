@@ -614,6 +614,28 @@ def toy_sample(kind, n, device, V=8, noise=0.2, seed=0, offset=0):
     return x, k
 
 
+def toy_generate(mlp, mi, x, k, times, dt, thermo_kind, gamma, delta_n=None, seed=0, offset=0, em_sigma=None,
+                 delta_w=None):
+    """In-place generation loop of the toy MultiModalMLP on x (B,N,2) f32 and k (B,N,1) int64: one launch."""
+    ws = [mlp.body[0].weight, mlp.body[0].bias, mlp.body[2].weight, mlp.body[2].bias, mlp.body[4].weight,
+          mlp.body[4].bias, mlp.body[6].weight, mlp.body[6].bias, mlp.continous_head.weight, mlp.continous_head.bias,
+          mlp.discrete_head.weight, mlp.discrete_head.bias]
+    ptrs = (C.c_void_p * 12)()
+    keep = []
+    for i, w in enumerate(ws):
+        t = w.detach()
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise MMBError("toy_generate: parameters must be float32 HIP tensors (no CPU fallback)")
+        t = t.contiguous()
+        keep.append(t)
+        ptrs[i] = t.data_ptr()
+    table = mlp.embed.weight.detach().contiguous()
+    call("mmb_toy_generate", mi.B, mi.N, mlp.dim_hidden, mlp.dim, mlp.vocab_size, f32(table, "table"), ptrs,
+         f32(mi.maskf), f32(x, "x"), i64(k, "k"), times.numel(), f32(times, "times"), _fl(dt), thermo_kind, _fl(gamma),
+         f32(delta_n, "delta_n"), seed, offset, 0 if em_sigma is None else 1, _fl(0.0 if em_sigma is None else em_sigma),
+         f32(delta_w, "delta_w"), stream())
+
+
 # ------------------------------------------------------------------------ AOJ reader (SURVEY 8f.4)
 def aoj_features(pfcands):
     """raw PFCands (J,M,F) f32 on device -> (feats (J,M,3) = pt, eta_rel, phi_rel; tokens (J,M,1) i64; mask (J,M,1) i64)"""

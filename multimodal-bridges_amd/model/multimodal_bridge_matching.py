@@ -417,6 +417,30 @@ class MultiModalBridgeMatching(nn.Module):
                                 ctab=ctab, em_sigma=em_sigma, delta_w=dw)
             state.time = torch.full((mi.B, mi.N, 1), times[-1], device=dev)
             return TensorMultiModal.stack([first, state], dim=0)
+        enc = self.encoder
+        if (self.raw_state and self.use_fused and type(enc).__name__ == "MultiModalMLP" and only_dn
+                and (enc.dim_hidden, enc.dim, enc.vocab_size) == (64, 2, 8) and state.has_continuous and state.has_discrete
+                and cfg.solver_continuous in ("euler", "euler_maruyama") and cfg.solver_discrete == "tauleap"):
+            # the toy MLP: ONE launch for the whole loop (the layered path below needs 16 per grid point)
+            dev = state.mask.device
+
+            def inj(name):
+                if not noise or name not in noise:
+                    return None
+                v = noise[name]
+                return (torch.stack(list(v), 0) if isinstance(v, (list, tuple)) else v).contiguous().float()
+
+            em_sigma = None
+            if cfg.solver_continuous == "euler_maruyama":
+                bc = self.bridge_continuous
+                em_sigma = float(bc.sigma) if getattr(bc, "kind", 0) == 1 else 0.0
+            br = self.bridge_discrete
+            state.continuous = state.continuous.contiguous().float()
+            ops.toy_generate(enc, mi, state.continuous, state.discrete, grid.to(dev), delta_t, br.thermo_kind, br.gamma,
+                             delta_n=inj("delta_n"), seed=self.seed, offset=(call_id << 16), em_sigma=em_sigma,
+                             delta_w=inj("delta_w") if em_sigma is not None else None)
+            state.time = torch.full((mi.B, mi.N, 1), times[-1], device=dev)
+            return TensorMultiModal.stack([first, state], dim=0)
         was_training = self.training
         self.eval()
         rates = None

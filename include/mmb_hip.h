@@ -244,6 +244,20 @@ int mmb_linear_cat(int M, int rows_per_jet, int n_seg,
                    int post_act, float drop_p, uint64_t seed, uint64_t offset,
                    const float* res2, int64_t res2_ld, float* Y2, int64_t y2_ld, void* stream);
 
+/* The post-LN sublayers of nn.TransformerEncoderLayer (particle_transformer.py:29-50; torch's
+ * x = norm1(x + sa(x)), x = norm2(x + ff(x))) in one call:
+ *   Y1  = act( cat_s[X_s] @ W^T + bias ) + residual      -> Y1 (M,Nout) | NULL (the reverse pass wants it)
+ *   Yln = LayerNorm(Y1) * gamma + beta                    -> Yln; stats (M,2) | NULL = (mean, 1/sqrt(var+eps)) per row
+ * Segment arguments as mmb_linear_cat.  For M > 4096 rows, 16-aligned segments and Nout in {32, 64, 128} with the
+ * weight block within 160 KB of LDS the normalisation runs in the epilogue of the row-streaming kernel (a wave owns
+ * whole rows); every other shape runs the linear kernel and mmb_layernorm_fwd back to back (Yln may then serve as
+ * the scratch of the first stage when Y1 is NULL).  Same results either way. */
+int mmb_linear_cat_ln(int M, int rows_per_jet, int n_seg, const void* const* seg_ptr_host,
+                      const int* seg_width_host, const int* seg_kind_host, const int* seg_ld_host,
+                      const float* maskf, const float* W, int64_t w_ld, const float* bias, int Nout, int act,
+                      const float* residual, int64_t res_ld, float* Y1, int64_t y1_ld, const float* gamma,
+                      const float* beta, float eps, float* Yln, int64_t yln_ld, float* stats, void* stream);
+
 /* EPiCEncoder._meansum_pool (epic.py:100-107) without the concat:
  * pooled[b, 0:H] = sum_n x*mask / counts[b] ; pooled[b, H:2H] = 0.01 * sum_n x*mask. */
 int mmb_meansum_pool(int B, int N, int H, const float* x, int64_t x_ld, const float* maskf,

@@ -47,6 +47,12 @@ struct Post {
   int act;
   float drop_p;
   uint64_t seed, offset;
+  // LayerNorm as the second stage (mmb_linear_cat_ln; row-streaming kernel with the whole row in one wave):
+  // Y2 = (Y1 - mean) * rstd * ln_gamma + ln_beta, ln_stats (M,2) | NULL = (mean, rstd)
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
+  float* ln_stats;
 };
 
 // inverted dropout with a Philox keep-mask indexed by the element (row*Nout+col)
@@ -98,58 +104,74 @@ __device__ __forceinline__ void apply_act16(int act, f32x16& v) {
   }
 }
 
-template <bool FULL>                             // FULL: all 32 rows of the tile exist (no per-row guards: the
-__device__ __forceinline__ void                  // loads of a stream are then issued back to back, one wait)
-epilogue_tile_body(f32x16 v, int row0, int col, int half, int M, int Nout, const float* __restrict__ bias, int act,
-                   const float* __restrict__ residual, int64_t res_ld, const float* __restrict__ row_scale,
-                   float* __restrict__ Y, int64_t y_ld, float* __restrict__ pre_act, const Post& post) {
-  // one pass per optional stream over the tile's 16 values (uniform branches OUTSIDE the element loops), each
-  // stream addressed from ONE 64-bit base per lane plus compile-time multiples of its row stride
-  const int rbase = row0 + 4 * half;
-  const int nrow = M - rbase;                  // rows of this lane's 16 that exist: offsets (i&3) + 8*(i>>2) < nrow
-  auto load16 = [&](const float* base, int64_t ld, f32x16& r) {
+// Epilogue of one 32x32 accumulator tile.  One pass per optional stream over the tile's 16 values (uniform branches
+// OUTSIDE the element loops), each stream addressed from ONE 64-bit base per lane plus compile-time multiples of its
+// row stride.  FULL: all 32 rows of the tile exist -- no per-row guards, so the loads of a stream are issued back to
+// back and awaited once (the per-element form compiled to ~500 branches and one awaited load per element).
+template <bool FULL>
+struct TileIO {
+  int rbase, nrow, col;                        // rows of this lane's 16 that exist: offsets (i&3) + 8*(i>>2) < nrow
+  __device__ __forceinline__ void load16(const float* base, int64_t ld, f32x16& r) const {
     const float* p = base + (int64_t)rbase * ld + col;
     static_for<16>([&](auto ic) {
       constexpr int i = decltype(ic)::v;
       constexpr int off = (i & 3) + 8 * (i >> 2);
       r[i] = (FULL || off < nrow) ? p[off * ld] : 0.0f;
     });
-  };
-  auto store16 = [&](float* base, int64_t ld, const f32x16& r) {
+  }
+  __device__ __forceinline__ void store16(float* base, int64_t ld, const f32x16& r) const {
     float* p = base + (int64_t)rbase * ld + col;
     static_for<16>([&](auto ic) {
       constexpr int i = decltype(ic)::v;
       constexpr int off = (i & 3) + 8 * (i >> 2);
       if (FULL || off < nrow) p[off * ld] = r[i];
     });
-  };
+  }
+};
+
+// first stage: v = act(v + bias) + residual [* row_scale] -> Y (and the pre-activation)
+template <bool FULL>
+__device__ __forceinline__ void
+epilogue_stage1(f32x16& v, const TileIO<FULL>& io, int Nout, const float* __restrict__ bias, int act,
+                const float* __restrict__ residual, int64_t res_ld, const float* __restrict__ row_scale,
+                float* __restrict__ Y, int64_t y_ld, float* __restrict__ pre_act) {
   f32x16 t;
-  const float bv = bias ? bias[col] : 0.0f;
+  const float bv = bias ? bias[io.col] : 0.0f;
   static_for<16>([&](auto ic) { v[decltype(ic)::v] += bv; });
-  if (pre_act) store16(pre_act, (int64_t)Nout, v);
+  if (pre_act) io.store16(pre_act, (int64_t)Nout, v);
   apply_act16(act, v);
   if (residual) {
-    load16(residual, res_ld, t);
+    io.load16(residual, res_ld, t);
     v += t;
   }
   if (row_scale) {
-    load16(row_scale - col, (int64_t)1, t);
+    io.load16(row_scale - io.col, (int64_t)1, t);
     v *= t;
   }
-  if (Y) store16(Y, y_ld, v);
+  if (Y) io.store16(Y, y_ld, v);
+}
+
+template <bool FULL>
+__device__ __forceinline__ void
+epilogue_tile_body(f32x16 v, int row0, int col, int half, int M, int Nout, const float* __restrict__ bias, int act,
+                   const float* __restrict__ residual, int64_t res_ld, const float* __restrict__ row_scale,
+                   float* __restrict__ Y, int64_t y_ld, float* __restrict__ pre_act, const Post& post) {
+  const TileIO<FULL> io{row0 + 4 * half, M - (row0 + 4 * half), col};
+  epilogue_stage1<FULL>(v, io, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld, pre_act);
   if (post.Y2) {
+    f32x16 t;
     apply_act16(post.act, v);
     if (post.drop_p > 0.0f)
       static_for<16>([&](auto ic) {
         constexpr int i = decltype(ic)::v;
         v[i] = dropout_apply(v[i], post.drop_p, post.seed, post.offset,
-                             (uint64_t)(rbase + (i & 3) + 8 * (i >> 2)) * Nout + col);
+                             (uint64_t)(io.rbase + (i & 3) + 8 * (i >> 2)) * Nout + col);
       });
     if (post.res2) {
-      load16(post.res2, post.res2_ld, t);
+      io.load16(post.res2, post.res2_ld, t);
       v += t;
     }
-    store16(post.Y2, post.y2_ld, v);
+    io.store16(post.Y2, post.y2_ld, v);
   }
 }
 
@@ -163,6 +185,72 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& v, int row0, int col
     epilogue_tile_body<true>(v, row0, col, half, M, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);
   else
     epilogue_tile_body<false>(v, row0, col, half, M, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);
+}
+
+// The wave owns WHOLE rows (Nout = 32 NT): first stage of every tile, then LayerNorm over the row -- a row lives in
+// register r of the 32 lanes of one lane half, NT tiles wide: two butterfly sums over the half (mean, then the
+// variance of the centred values, as mmb_layernorm_fwd) -- and the normalised row leaves as the second stage.
+// sum over the 32 lanes of a lane half, delivered to all of them: four DPP steps inside the rows of 16 (no LDS
+// crossbar: ds_bpermute for all five steps made the fused epilogue slower than a separate LayerNorm launch) and one
+// exchange between the two rows
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float half_sum32(float s) {
+  s += dpp_f<0xB1>(s);                         // quad_perm [1,0,3,2]
+  s += dpp_f<0x4E>(s);                         // quad_perm [2,3,0,1]
+  s += dpp_f<0x141>(s);                        // row_half_mirror: the other quad of the 8
+  s += dpp_f<0x140>(s);                        // row_mirror: the other 8 of the 16
+  s += __shfl_xor(s, 16, 64);
+  return s;
+}
+template <int NT, bool FULL>
+__device__ __forceinline__ void
+epilogue_rows_ln(f32x16 (&v)[NT], int row0, int col0, int r32, int half, int M, int Nout,
+                 const float* __restrict__ bias, int act, const float* __restrict__ residual, int64_t res_ld,
+                 const float* __restrict__ row_scale, float* __restrict__ Y, int64_t y_ld,
+                 float* __restrict__ pre_act, const Post& post) {
+  static_for<NT>([&](auto jc) {
+    constexpr int j = decltype(jc)::v;
+    const TileIO<FULL> io{row0 + 4 * half, M - (row0 + 4 * half), col0 + 32 * j + r32};
+    epilogue_stage1<FULL>(v[j], io, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld, pre_act);
+  });
+  const float inv_n = 1.0f / (float)(32 * NT);
+  f32x16 mean, rstd;
+  static_for<16>([&](auto ic) {
+    constexpr int i = decltype(ic)::v;
+    float s = 0.0f;
+    static_for<NT>([&](auto jc) { s += v[decltype(jc)::v][i]; });
+    mean[i] = half_sum32(s) * inv_n;
+  });
+  static_for<16>([&](auto ic) {
+    constexpr int i = decltype(ic)::v;
+    float q = 0.0f;
+    static_for<NT>([&](auto jc) { constexpr int j = decltype(jc)::v;
+      v[j][i] -= mean[i];
+      q = fmaf(v[j][i], v[j][i], q); });
+    rstd[i] = rsqrtf(half_sum32(q) * inv_n + post.ln_eps);
+  });
+  static_for<NT>([&](auto jc) {
+    constexpr int j = decltype(jc)::v;
+    const int col = col0 + 32 * j + r32;
+    const TileIO<FULL> io{row0 + 4 * half, M - (row0 + 4 * half), col};
+    const float gm = post.ln_gamma[col], bt = post.ln_beta[col];
+    static_for<16>([&](auto ic) { constexpr int i = decltype(ic)::v; v[j][i] = fmaf(v[j][i] * rstd[i], gm, bt); });
+    io.store16(post.Y2, post.y2_ld, v[j]);
+  });
+  if (post.ln_stats && r32 == 0) {
+    const int rbase = row0 + 4 * half;
+    static_for<16>([&](auto ic) {
+      constexpr int i = decltype(ic)::v;
+      constexpr int off = (i & 3) + 8 * (i >> 2);
+      if (FULL || rbase + off < M) {
+        post.ln_stats[2 * (int64_t)(rbase + off)] = mean[i];
+        post.ln_stats[2 * (int64_t)(rbase + off) + 1] = rstd[i];
+      }
+    });
+  }
 }
 
 template <int WAVES, int NT, int BK, bool ALIGNED>
@@ -596,11 +684,20 @@ linear_stream_x6_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __
       consume(bufB, scaleB, 2 * p + 1);
     }
     const int row0 = t * 32;
-    static_for<NT>([&](auto jc) {
-      constexpr int j = decltype(jc)::v;
-      epilogue_tile(acc[j], row0, col0 + j * 32 + r32, half, M, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld,
-                    pre_act, post);
-    });
+    if (post.ln_gamma != nullptr) {             // (the host launches this only with Nout == 32 NT, one column block)
+      if (row0 + 32 <= M)
+        epilogue_rows_ln<NT, true>(acc, row0, col0, r32, half, M, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld,
+                                   pre_act, post);
+      else
+        epilogue_rows_ln<NT, false>(acc, row0, col0, r32, half, M, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld,
+                                    pre_act, post);
+    } else {
+      static_for<NT>([&](auto jc) {
+        constexpr int j = decltype(jc)::v;
+        epilogue_tile(acc[j], row0, col0 + j * 32 + r32, half, M, Nout, bias, act, residual, res_ld, row_scale, Y,
+                      y_ld, pre_act, post);
+      });
+    }
   }
 }
 
@@ -881,17 +978,16 @@ static int linear_path() {
 
 using namespace mmb;
 
-extern "C" int mmb_linear_cat(int M, int rows_per_jet, int n_seg, const void* const* seg_ptr, const int* seg_width,
-                              const int* seg_kind, const int* seg_ld, const float* maskf, const float* W,
-                              int64_t w_ld, const float* bias, int Nout, int act, const float* residual,
-                              int64_t res_ld, const float* row_scale, float* Y, int64_t y_ld, float* pre_act,
-                              int post_act, float drop_p, uint64_t seed, uint64_t offset, const float* res2,
-                              int64_t res2_ld, float* Y2, int64_t y2_ld, void* stream) {
-  MMB_REQUIRE(M > 0 && Nout > 0, "mmb_linear_cat: empty shape M=%d Nout=%d", M, Nout);
-  MMB_REQUIRE(Y || Y2, "mmb_linear_cat: no output given");
-  MMB_REQUIRE(post_act >= 0 && post_act <= 3, "mmb_linear_cat: bad post activation %d", post_act);   // (SELU: first stage only)
-  MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_linear_cat: dropout p=%f outside [0,1)", drop_p);
-  Post post{Y2, y2_ld, res2, res2_ld, post_act, drop_p, seed, offset};
+// shared body of mmb_linear_cat / mmb_linear_cat_ln.  ln: a LayerNorm second stage is wanted (post.ln_*, post.Y2);
+// *ln_done tells whether the launched kernel did it (row-streaming kernel, whole rows per wave) -- if not, the
+// first stage went to Y (or, without a Y, to post.Y2 as scratch) and the caller runs mmb_layernorm_fwd on it.
+static int linear_cat_impl(int M, int rows_per_jet, int n_seg, const void* const* seg_ptr, const int* seg_width,
+                           const int* seg_kind, const int* seg_ld, const float* maskf, const float* W, int64_t w_ld,
+                           const float* bias, int Nout, int act, const float* residual, int64_t res_ld,
+                           const float* row_scale, float* Y, int64_t y_ld, float* pre_act, Post post, bool* ln_done,
+                           void* stream) {
+  const bool want_ln = post.ln_gamma != nullptr;
+  if (ln_done) *ln_done = false;
   MMB_REQUIRE(rows_per_jet > 0, "mmb_linear_cat: rows_per_jet must be > 0");
   MMB_REQUIRE(n_seg >= 1 && n_seg <= 4, "mmb_linear_cat: n_seg=%d outside [1,4]", n_seg);
   MMB_REQUIRE(seg_ptr && seg_width && seg_kind && seg_ld && W, "mmb_linear_cat: NULL argument");
@@ -920,6 +1016,20 @@ extern "C" int mmb_linear_cat(int M, int rows_per_jet, int n_seg, const void* co
   al16 = al16 && w_al;
   al8 = al8 && w_al;
   hipStream_t st = as_stream(stream);
+  const int lpath = linear_path();
+  bool ln_stream = false;
+  if (want_ln) {       // only the bf16x6 row-streaming kernel normalises, and only with the whole row in one wave
+    const int KP2 = (K + 63) & ~63;
+    const char* e = getenv("MMB_LN_FUSE");       // A/B switch: "0" = always linear kernel + mmb_layernorm_fwd
+    ln_stream = !(e && e[0] == '0') && M > 4096 && al16 && lpath == 2 && (Nout == 32 || Nout == 64 || Nout == 128) &&
+                (size_t)3 * Nout * (KP2 + 8) * sizeof(unsigned short) <= 160 * 1024;
+    if (!ln_stream) {  // first stage only: into Y, or into the LN output as scratch (the caller normalises in place)
+      if (!Y) { Y = post.Y2; y_ld = post.y2_ld; }
+      post.Y2 = nullptr;
+      post.ln_gamma = post.ln_beta = nullptr;
+      post.ln_stats = nullptr;
+    }
+  }
   // per-jet layers (one ROW segment, few rows): split-K kernel, one 32x32 tile per block
   const bool al4 = (seg_ld[0] % 4 == 0) && ((reinterpret_cast<uintptr_t>(seg_ptr[0]) & 15) == 0) && w_al;
   if (M <= 4096 && n_seg == 1 && seg_kind[0] == MMB_SEG_ROW && K % 4 == 0 && K <= 8 * 4 * 12 && al4) {
@@ -945,7 +1055,6 @@ extern "C" int mmb_linear_cat(int M, int rows_per_jet, int n_seg, const void* co
     return check_launch("mmb_linear_cat");
   }
   const bool small_m = M <= 4096;                // per-jet rows: one wave per block for parallelism
-  const int lpath = linear_path();
   if (!small_m && al16 && lpath != 0) {
     // row-streaming kernels: the widest column block (tiles of 32 columns) that pads Nout least and fits LDS
     const bool x6 = lpath == 2;
@@ -964,7 +1073,12 @@ extern "C" int mmb_linear_cat(int M, int rows_per_jet, int n_seg, const void* co
         snt = c;
       }
     }
+    if (ln_stream) {                             // whole rows in one wave: Nout = 32 * snt exactly, one column block
+      snt = Nout / 32;
+      best_pad = Nout;
+    }
     if (snt) {
+      if (ln_stream && ln_done) *ln_done = true;
       const int gy = best_pad / (32 * snt), ntiles = (M + 31) / 32, cus = cu_count();
       int gx = cus / gy / 8 * 8;                 // same-x blocks (same rows, other columns) land on one XCD's L2
       if (gx < 8) gx = cus / gy > 0 ? cus / gy : 1;
@@ -1020,6 +1134,39 @@ extern "C" int mmb_linear_cat(int M, int rows_per_jet, int n_seg, const void* co
 #undef MMB_PICK_NT
 #undef MMB_LAUNCH
   return check_launch("mmb_linear_cat");
+}
+
+extern "C" int mmb_linear_cat(int M, int rows_per_jet, int n_seg, const void* const* seg_ptr, const int* seg_width,
+                              const int* seg_kind, const int* seg_ld, const float* maskf, const float* W,
+                              int64_t w_ld, const float* bias, int Nout, int act, const float* residual,
+                              int64_t res_ld, const float* row_scale, float* Y, int64_t y_ld, float* pre_act,
+                              int post_act, float drop_p, uint64_t seed, uint64_t offset, const float* res2,
+                              int64_t res2_ld, float* Y2, int64_t y2_ld, void* stream) {
+  MMB_REQUIRE(M > 0 && Nout > 0, "mmb_linear_cat: empty shape M=%d Nout=%d", M, Nout);
+  MMB_REQUIRE(Y || Y2, "mmb_linear_cat: no output given");
+  MMB_REQUIRE(post_act >= 0 && post_act <= 3, "mmb_linear_cat: bad post activation %d", post_act);   // (SELU: first stage only)
+  MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_linear_cat: dropout p=%f outside [0,1)", drop_p);
+  Post post{Y2, y2_ld, res2, res2_ld, post_act, drop_p, seed, offset, nullptr, nullptr, 0.0f, nullptr};
+  return linear_cat_impl(M, rows_per_jet, n_seg, seg_ptr, seg_width, seg_kind, seg_ld, maskf, W, w_ld, bias, Nout, act,
+                         residual, res_ld, row_scale, Y, y_ld, pre_act, post, nullptr, stream);
+}
+
+extern "C" int mmb_linear_cat_ln(int M, int rows_per_jet, int n_seg, const void* const* seg_ptr, const int* seg_width,
+                                 const int* seg_kind, const int* seg_ld, const float* maskf, const float* W,
+                                 int64_t w_ld, const float* bias, int Nout, int act, const float* residual,
+                                 int64_t res_ld, float* Y1, int64_t y1_ld, const float* gamma, const float* beta,
+                                 float eps, float* Yln, int64_t yln_ld, float* stats, void* stream) {
+  MMB_REQUIRE(M > 0 && Nout > 0, "mmb_linear_cat_ln: empty shape M=%d Nout=%d", M, Nout);
+  MMB_REQUIRE(gamma && beta && Yln && yln_ld >= Nout, "mmb_linear_cat_ln: NULL gamma / beta / output");
+  MMB_REQUIRE(!Y1 || y1_ld >= Nout, "mmb_linear_cat_ln: y1 row stride < Nout");
+  Post post{Yln, yln_ld, nullptr, 0, MMB_ACT_NONE, 0.0f, 0, 0, gamma, beta, eps, stats};
+  bool done = false;
+  if (int rc = linear_cat_impl(M, rows_per_jet, n_seg, seg_ptr, seg_width, seg_kind, seg_ld, maskf, W, w_ld, bias, Nout,
+                               act, residual, res_ld, nullptr, Y1, y1_ld, nullptr, post, &done, stream))
+    return rc;
+  if (done) return MMB_OK;
+  // this shape is not served by the fused epilogue: the first stage is in Y1 (or in Yln), normalise it (in place)
+  return mmb_layernorm_fwd(M, Nout, Y1 ? Y1 : Yln, Y1 ? y1_ld : yln_ld, gamma, beta, eps, Yln, yln_ld, stats, stream);
 }
 
 extern "C" int mmb_weight_norm(int n_rows, const int32_t* row_off, const int32_t* row_len, const float* v,

@@ -60,22 +60,22 @@ class PlainLinear:
         self.weight()
         return self._cache[2]
 
-    def run(self, ctx, segs, act=None, res1=None, out=None):
-        """y = act(cat(segs) @ W^T + b) + res1."""
+    def run(self, ctx, segs, act=None, res1=None, out=None, norm=None):
+        """y = act(cat(segs) @ W^T + b) + res1;  with norm (an nn.LayerNorm): LayerNorm(y), in the same call
+        (mmb_linear_cat_ln: the post-LN sublayer of nn.TransformerEncoderLayer)."""
         W = self.weight()
-        y = ops.linear_cat(segs, W, self.bias(), ctx.N, maskf=ctx.mi.maskf, act=act, residual=res1, out=out)
-        if ctx.recording:
-            ctx.tape.append(("plinear", self, ctx.N, segs, act, res1, None, None, None, y, None, 0.0, 0))
+        if norm is None:
+            y = ops.linear_cat(segs, W, self.bias(), ctx.N, maskf=ctx.mi.maskf, act=act, residual=res1, out=out)
+            if ctx.recording:
+                ctx.tape.append(("plinear", self, ctx.N, segs, act, res1, None, None, None, y, None, 0.0, 0))
+            return y
+        rec = ctx.recording
+        y1, y, stats = ops.linear_cat_ln(segs, W, self.bias(), ctx.N, norm.weight.detach(), norm.bias.detach(), norm.eps,
+                                         maskf=ctx.mi.maskf, act=act, residual=res1, want_y1=rec, want_stats=rec, out=out)
+        if rec:                                           # the same two tape entries as the unfused pair
+            ctx.tape.append(("plinear", self, ctx.N, segs, act, res1, None, None, None, y1, None, 0.0, 0))
+            ctx.tape.append(("ln", y1, y, stats, norm))
         return y
-
-
-def layer_norm(ctx, x, norm, out=None):
-    rec = ctx.recording
-    r = ops.layernorm_fwd(x, norm.weight.detach(), norm.bias.detach(), norm.eps, want_stats=rec, out=out)
-    if rec:
-        ctx.tape.append(("ln", x, r[0], r[1], norm))
-        return r[0]
-    return r
 
 
 class TransformerEncoderBlock(nn.Module):
@@ -121,11 +121,9 @@ class TransformerEncoderBlock(nn.Module):
             a = r[0] if rec else r
             if rec:
                 ctx.tape.append(("attn", qkv, a, r[1], self.n_heads))
-            s1 = out_proj.run(ctx, [(a, SEG_ROW)], res1=h)
-            h1 = layer_norm(ctx, s1, norm1)
+            h1 = out_proj.run(ctx, [(a, SEG_ROW)], res1=h, norm=norm1)
             f = lin1.run(ctx, [(h1, SEG_ROW)], act="relu")
-            s2 = lin2.run(ctx, [(f, SEG_ROW)], res1=h1)
-            h = layer_norm(ctx, s2, norm2, out=out if i == len(layers) - 1 else None)
+            h = lin2.run(ctx, [(f, SEG_ROW)], res1=h1, norm=norm2, out=out if i == len(layers) - 1 else None)
         if not layers and out is not None:
             out.copy_(h)
             h = out

@@ -288,6 +288,33 @@ def linear_cat(segs, W, bias, rows_per_jet, maskf=None, act=None, residual=None,
     return res
 
 
+def linear_cat_ln(segs, W, bias, rows_per_jet, gamma, beta, eps, maskf=None, act=None, residual=None, want_y1=False,
+                  want_stats=False, out=None):
+    """y1 = act(cat(segs) @ W^T + b) + residual ; y = LayerNorm(y1) * gamma + beta  (one call: the normalisation runs
+    in the linear kernel's epilogue where a wave owns whole rows).  Returns (y1 | None, y, stats | None)."""
+    for t, _ in segs:
+        if t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda or t.dtype != torch.float32:
+            raise MMBError("linear_cat_ln: segments must be 2-D float32 HIP tensors with unit inner stride (no CPU fallback)")
+    n, ptrs, widths, kinds, lds, M = _seg_arrays(segs)
+    if M is None:
+        raise MMBError("linear_cat_ln: at least one ROW segment is required")
+    if W.dim() != 2 or W.stride(1) != 1 or not W.is_cuda or W.dtype != torch.float32:
+        raise MMBError("linear_cat_ln: W must be a 2-D float32 HIP tensor with unit inner stride")
+    Nout = W.shape[0]
+    dev = W.device
+    y1 = torch.empty(M, Nout, dtype=torch.float32, device=dev) if want_y1 else None
+    y = torch.empty(M, Nout, dtype=torch.float32, device=dev) if out is None else out
+    stats = torch.empty(M, 2, dtype=torch.float32, device=dev) if want_stats else None
+    rp, rl = (residual.data_ptr(), residual.stride(0)) if residual is not None else (None, 0)
+    if _m.PROFILE is not None:
+        _m.PROFILE_META = {"M": M, "K": sum(widths), "Nout": Nout, "flops": 2.0 * M * sum(widths) * Nout}
+    call("mmb_linear_cat_ln", M, rows_per_jet, n, ptrs, widths, kinds, lds, f32(maskf, "maskf"), W.data_ptr(), W.stride(0),
+         f32(bias, "bias"), Nout, ACT[act], rp, rl, f32(y1), Nout if y1 is not None else 0, f32(gamma, "gamma"),
+         f32(beta, "beta"), _fl(eps), y.data_ptr(), y.stride(0), f32(stats), stream())
+    _m.PROFILE_META = None
+    return y1, y, stats
+
+
 def meansum_pool(x, mi, out=None):
     """x: (B*N, H) rows (row stride may exceed H) -> pooled (B, 2H) = [mean, 0.01*sum]."""
     B, N = mi.B, mi.N

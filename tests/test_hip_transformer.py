@@ -154,3 +154,40 @@ def test_transformer_refuses_dropout_in_training(golden):
     state = TensorMultiModal(t["time"].cuda(), t["xt"].cuda(), t["kt"].cuda(), t["mask"].cuda())
     with pytest.raises(NotImplementedError):
         model(state, None)
+
+
+@pytest.mark.parametrize("M,K,Nout", [(6000, 64, 64), (6000, 256, 64), (4100, 128, 128), (6000, 256, 128),
+                                      (300, 64, 64), (6000, 64, 96), (5000, 48, 32)])
+@pytest.mark.parametrize("path", ["x6", "tiled"])
+def test_linear_cat_ln(M, K, Nout, path, monkeypatch):
+    """mmb_linear_cat_ln = LayerNorm(act(x W^T + b) + residual) in one call: normalised in the epilogue of the
+    row-streaming kernel where a wave owns whole rows (the first three shapes and the last under x6), by the linear
+    kernel + mmb_layernorm_fwd otherwise (weight block beyond LDS, few rows, ragged width, MMB_LINEAR_PATH=tiled) --
+    the same function either way, against fp64."""
+    from mmb_hip import ops
+    monkeypatch.setenv("MMB_LINEAR_PATH", path)
+    g = torch.Generator().manual_seed(M + K + Nout)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(Nout, K, generator=g) / math.sqrt(K)
+    b, gamma, beta = torch.randn(Nout, generator=g), torch.randn(Nout, generator=g), torch.randn(Nout, generator=g)
+    res = torch.randn(M, Nout, generator=g)
+    z = torch.nn.functional.linear(x.double(), W.double(), b.double()).relu() + res.double()
+    want = torch.nn.functional.layer_norm(z, (Nout,), gamma.double(), beta.double(), 1e-5)
+    segs = [(x.cuda(), ops.SEG_ROW)]
+    y1, y, stats = ops.linear_cat_ln(segs, W.cuda(), b.cuda(), 50, gamma.cuda(), beta.cuda(), 1e-5, act="relu",
+                                     residual=res.cuda(), want_y1=True, want_stats=True)
+    close(y1, z, rtol=1e-4, atol=2e-5)
+    close(y, want, rtol=1e-4, atol=5e-5)
+    close(stats[:, 0], z.mean(1), rtol=1e-4, atol=1e-5)
+    close(stats[:, 1], 1.0 / torch.sqrt(z.var(1, unbiased=False) + 1e-5), rtol=1e-4, atol=1e-5)
+    # without y1 / stats, into a column slice of a wider buffer
+    wide = torch.zeros(M, Nout + 8, device="cuda")
+    n1, y2, s2 = ops.linear_cat_ln(segs, W.cuda(), b.cuda(), 50, gamma.cuda(), beta.cuda(), 1e-5, act="relu",
+                                   residual=res.cuda(), out=wide[:, 4:4 + Nout])
+    assert n1 is None and s2 is None
+    close(wide[:, 4:4 + Nout], want, rtol=1e-4, atol=5e-5)
+    assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + Nout:].abs().max()) == 0.0
+    # the backward's LayerNorm entry takes (y1, stats) as mmb_layernorm_fwd would have produced them
+    ref_y, ref_stats = ops.layernorm_fwd(y1, gamma.cuda(), beta.cuda(), 1e-5, want_stats=True)
+    close(y, ref_y, rtol=1e-5, atol=1e-5)
+    close(stats, ref_stats, rtol=1e-5, atol=1e-6)

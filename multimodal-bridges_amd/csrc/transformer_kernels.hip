@@ -361,7 +361,7 @@ __device__ __forceinline__ void jet_head_of_block(int nh, int& b, int& h) {
 }
 
 template <int DH, bool VEC>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DH == 16 ? 8 : 6)))
 attn_fwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int64_t ld,
                      const float* __restrict__ maskf, int valid_is_zero, float scale, float* __restrict__ out,
                      int64_t out_ld, float* __restrict__ lse) {
@@ -400,11 +400,6 @@ attn_fwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv
       const float* kr = Ks + (kt + col) * P + par * HD;
 #pragma unroll
       for (int i = 0; i < HD; ++i) s = MMB_MFMA_F32(kr[i], qr[i], s);
-      float va[DT][16];                          // the V operands of the second product: in flight during the softmax
-#pragma unroll
-      for (int t = 0; t < DT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) va[t][r] = Vs[(kt + crow(r, par)) * P + t * 32 + col];
       if (kt + 32 > nk) {                        // only the last tile has keys to mask
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -430,7 +425,8 @@ attn_fwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t] = MMB_MFMA_F32(va[t][r], s[r], acc[t]);
+        for (int r = 0; r < 16; ++r)
+          acc[t] = MMB_MFMA_F32(Vs[(kt + crow(r, par)) * P + t * 32 + col], s[r], acc[t]);
       }
     }
     if (q < N) {

@@ -182,10 +182,11 @@ def test_loss_fwd_bwd(ops):
     (4100, 1, [272], [0], 100, "lrelu"),                         # ragged everything, K % 32 = 16
     (4200, 100, [1280, 32], [0, 1], 40, None),                   # K too wide for a resident weight block: tiled kernel
 ])
-@pytest.mark.parametrize("path", ["stream", "tiled"])
+@pytest.mark.parametrize("path", ["x6", "stream", "tiled"])
 def test_linear_cat(ops, M, N, widths, kinds, Nout, act, path, monkeypatch):
-    """path: M > 4096 rows with 16-aligned segments run the row-streaming kernel (weight block resident in LDS)
-    unless MMB_LINEAR_PATH=tiled; every other shape runs the same kernel under both values."""
+    """path: M > 4096 rows with 16-aligned segments run a row-streaming kernel (weight block resident in LDS): x6 = the
+    default, six bf16-plane products per fp32 product; stream = the same on the fp32 MFMA; tiled = the block-tiled
+    fp32-MFMA kernel.  Every other shape runs the same kernel under all three values."""
     monkeypatch.setenv("MMB_LINEAR_PATH", path)
     g = torch.Generator().manual_seed(M + Nout)
     B = M // N
@@ -329,10 +330,14 @@ def test_invalid_arguments_raise(ops):
 
 @pytest.mark.parametrize("M,K,Nout,x_pad", [
     (131, 64, 64, 0), (4096, 64, 64, 8), (1024, 288, 128, 0), (777, 16, 3, 0), (2049, 128, 128, 32),
-    (64, 37, 70, 3), (5000, 144, 64, 0), (300, 128, 8, 0)])
-def test_grad_weight_rows(ops, M, K, Nout, x_pad):
-    """Row-streaming weight gradient against a plain torch fp32 matmul (ragged rows/columns, strided X,
+    (64, 37, 70, 3), (5000, 144, 64, 0), (300, 128, 8, 0), (70000, 80, 96, 0), (66000, 256, 128, 8)])
+@pytest.mark.parametrize("gw_path", ["x6", "f32"])
+def test_grad_weight_rows(ops, M, K, Nout, x_pad, gw_path, monkeypatch):
+    """(gw_path: six bf16-plane products per fp32 product, the default, or the fp32 MFMA: MMB_GW_PATH.  The two long
+    streams take the 4-tile / 1024-row blocks with two chunks in flight and ragged K / output windows.)
+    Row-streaming weight gradient against a plain torch fp32 matmul (ragged rows/columns, strided X,
     dW written into a column slice of a wider gradient, atomic accumulation on top of existing values)."""
+    monkeypatch.setenv("MMB_GW_PATH", gw_path)
     g = torch.Generator().manual_seed(M + K + Nout)
     Xfull = torch.randn(M, K + x_pad, generator=g).cuda()
     X = Xfull[:, x_pad:] if x_pad else Xfull

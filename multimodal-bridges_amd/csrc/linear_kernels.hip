@@ -53,6 +53,10 @@ struct Post {
   const float* ln_beta;
   float ln_eps;
   float* ln_stats;
+  // gate of the first stage (mmb_linear_cat_gate: the reverse pass of a ReLU layer folded into the GEMM that
+  // produces its output gradient): v = gate > 0 ? v : 0, applied after the residual
+  const float* gate;
+  int64_t gate_ld;
 };
 
 // inverted dropout with a Philox keep-mask indexed by the element (row*Nout+col)
@@ -134,7 +138,7 @@ template <bool FULL>
 __device__ __forceinline__ void
 epilogue_stage1(f32x16& v, const TileIO<FULL>& io, int Nout, const float* __restrict__ bias, int act,
                 const float* __restrict__ residual, int64_t res_ld, const float* __restrict__ row_scale,
-                float* __restrict__ Y, int64_t y_ld, float* __restrict__ pre_act) {
+                float* __restrict__ Y, int64_t y_ld, float* __restrict__ pre_act, const Post& post) {
   f32x16 t;
   const float bv = bias ? bias[io.col] : 0.0f;
   static_for<16>([&](auto ic) { v[decltype(ic)::v] += bv; });
@@ -148,6 +152,10 @@ epilogue_stage1(f32x16& v, const TileIO<FULL>& io, int Nout, const float* __rest
     io.load16(row_scale - io.col, (int64_t)1, t);
     v *= t;
   }
+  if (post.gate) {
+    io.load16(post.gate, post.gate_ld, t);
+    static_for<16>([&](auto ic) { constexpr int i = decltype(ic)::v; v[i] = t[i] > 0.0f ? v[i] : 0.0f; });
+  }
   if (Y) io.store16(Y, y_ld, v);
 }
 
@@ -157,7 +165,7 @@ epilogue_tile_body(f32x16 v, int row0, int col, int half, int M, int Nout, const
                    const float* __restrict__ residual, int64_t res_ld, const float* __restrict__ row_scale,
                    float* __restrict__ Y, int64_t y_ld, float* __restrict__ pre_act, const Post& post) {
   const TileIO<FULL> io{row0 + 4 * half, M - (row0 + 4 * half), col};
-  epilogue_stage1<FULL>(v, io, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld, pre_act);
+  epilogue_stage1<FULL>(v, io, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);
   if (post.Y2) {
     f32x16 t;
     apply_act16(post.act, v);
@@ -214,7 +222,7 @@ epilogue_rows_ln(f32x16 (&v)[NT], int row0, int col0, int r32, int half, int M, 
   static_for<NT>([&](auto jc) {
     constexpr int j = decltype(jc)::v;
     const TileIO<FULL> io{row0 + 4 * half, M - (row0 + 4 * half), col0 + 32 * j + r32};
-    epilogue_stage1<FULL>(v[j], io, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld, pre_act);
+    epilogue_stage1<FULL>(v[j], io, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);
   });
   const float inv_n = 1.0f / (float)(32 * NT);
   f32x16 mean, rstd;
@@ -1146,9 +1154,20 @@ extern "C" int mmb_linear_cat(int M, int rows_per_jet, int n_seg, const void* co
   MMB_REQUIRE(Y || Y2, "mmb_linear_cat: no output given");
   MMB_REQUIRE(post_act >= 0 && post_act <= 3, "mmb_linear_cat: bad post activation %d", post_act);   // (SELU: first stage only)
   MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_linear_cat: dropout p=%f outside [0,1)", drop_p);
-  Post post{Y2, y2_ld, res2, res2_ld, post_act, drop_p, seed, offset, nullptr, nullptr, 0.0f, nullptr};
+  Post post{Y2, y2_ld, res2, res2_ld, post_act, drop_p, seed, offset, nullptr, nullptr, 0.0f, nullptr, nullptr, 0};
   return linear_cat_impl(M, rows_per_jet, n_seg, seg_ptr, seg_width, seg_kind, seg_ld, maskf, W, w_ld, bias, Nout, act,
                          residual, res_ld, row_scale, Y, y_ld, pre_act, post, nullptr, stream);
+}
+
+extern "C" int mmb_linear_cat_gate(int M, int rows_per_jet, int n_seg, const void* const* seg_ptr,
+                                   const int* seg_width, const int* seg_kind, const int* seg_ld, const float* maskf,
+                                   const float* W, int64_t w_ld, int Nout, const float* gate, int64_t gate_ld, float* Y,
+                                   int64_t y_ld, void* stream) {
+  MMB_REQUIRE(M > 0 && Nout > 0, "mmb_linear_cat_gate: empty shape M=%d Nout=%d", M, Nout);
+  MMB_REQUIRE(gate && Y && gate_ld >= Nout && y_ld >= Nout, "mmb_linear_cat_gate: NULL gate / output or row stride < Nout");
+  Post post{nullptr, 0, nullptr, 0, MMB_ACT_NONE, 0.0f, 0, 0, nullptr, nullptr, 0.0f, nullptr, gate, gate_ld};
+  return linear_cat_impl(M, rows_per_jet, n_seg, seg_ptr, seg_width, seg_kind, seg_ld, maskf, W, w_ld, nullptr, Nout,
+                         MMB_ACT_NONE, nullptr, 0, nullptr, Y, y_ld, nullptr, post, nullptr, stream);
 }
 
 extern "C" int mmb_linear_cat_ln(int M, int rows_per_jet, int n_seg, const void* const* seg_ptr, const int* seg_width,
@@ -1159,7 +1178,7 @@ extern "C" int mmb_linear_cat_ln(int M, int rows_per_jet, int n_seg, const void*
   MMB_REQUIRE(M > 0 && Nout > 0, "mmb_linear_cat_ln: empty shape M=%d Nout=%d", M, Nout);
   MMB_REQUIRE(gamma && beta && Yln && yln_ld >= Nout, "mmb_linear_cat_ln: NULL gamma / beta / output");
   MMB_REQUIRE(!Y1 || y1_ld >= Nout, "mmb_linear_cat_ln: y1 row stride < Nout");
-  Post post{Yln, yln_ld, nullptr, 0, MMB_ACT_NONE, 0.0f, 0, 0, gamma, beta, eps, stats};
+  Post post{Yln, yln_ld, nullptr, 0, MMB_ACT_NONE, 0.0f, 0, 0, gamma, beta, eps, stats, nullptr, 0};
   bool done = false;
   if (int rc = linear_cat_impl(M, rows_per_jet, n_seg, seg_ptr, seg_width, seg_kind, seg_ld, maskf, W, w_ld, bias, Nout,
                                act, residual, res_ld, nullptr, Y1, y1_ld, nullptr, post, &done, stream))

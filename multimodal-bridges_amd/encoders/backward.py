@@ -15,6 +15,8 @@ matching slice of the buffer's gradient.  Parameters that take no part in the fo
 truncated embedding, quirk Q1; the never-executed last fused layer, K2) keep grad None, as
 in the reference.
 """
+import os
+
 import torch
 
 from mmb_hip import ops
@@ -27,6 +29,7 @@ GW_REPLICAS = 8
 class GradStore:
     def __init__(self):
         self.bufs = {}
+        self.relu_gates, self.gated = set(), set()      # (see _relu_gates)
 
     @staticmethod
     def _key(t):
@@ -126,6 +129,42 @@ def _produced(tape):
             if e[5] is not None:
                 keys.add(k(e[5]))
     return keys
+
+
+def _relu_gates(tape):
+    """Keys of ReLU-layer outputs whose reverse pass can be folded into their consumer's input-gradient GEMM
+    (mmb_linear_cat_gate): plain first stage (no residual, no second stage), read exactly once on the tape, and that by
+    a Linear as a per-particle ROW segment."""
+    if os.environ.get("MMB_RELU_GATE") == "0":         # A/B switch: mmb_act_bwd for every activation
+        return set()
+    k = GradStore._key
+    uses, row_uses = {}, {}
+
+    def use(t, row=False):
+        if t is not None:
+            uses[k(t)] = uses.get(k(t), 0) + 1
+            if row:
+                row_uses[k(t)] = row_uses.get(k(t), 0) + 1
+
+    for e in tape:
+        if e[0] in ("linear", "plinear"):
+            for t, kind in e[3]:
+                use(t, kind == SEG_ROW)
+            use(e[5])
+            use(e[7])
+        elif e[0] in ("attn", "ln", "pool"):
+            use(e[1])
+        elif e[0] == "cat":
+            for part in e[1]:
+                use(part)
+    gates = set()
+    for e in tape:
+        if e[0] in ("linear", "plinear") and e[4] == "relu" and e[5] is None and e[6] is None and e[10] is None \
+                and e[9] is not None and GradStore._owns_storage(e[9]):
+            key = k(e[9])
+            if uses.get(key, 0) == 1 and row_uses.get(key, 0) == 1:
+                gates.add(key)
+    return gates
 
 
 def _direct(p, touched):
@@ -237,6 +276,8 @@ def _linear_bwd(e, store, produced, mi, seed, arena, touched):
     M, Nout = ref.shape
     if act is None and gY2 is None:
         dZ = gY1                        # identity first stage, no gradient through the second: nothing to compute
+    elif y1 is not None and GradStore._key(y1) in store.gated:
+        dZ = gY1                        # its consumer's GEMM already applied relu' (mmb_linear_cat_gate)
     else:
         dZ = ops.act_bwd(M, Nout, gY1, gY2, y1, y2, res2, pre, act, post, p, seed, off)
     if res2 is not None and gY2 is not None and GradStore._key(res2) in produced:
@@ -268,7 +309,10 @@ def _linear_bwd(e, store, produced, mi, seed, arena, touched):
             gx, fresh = store.target(t)
             res = None if fresh else gx
             Wseg = WT[koff:koff + Ks]
-            if kind == SEG_ROW:
+            if kind == SEG_ROW and fresh and GradStore._key(t) in store.relu_gates:
+                ops.linear_cat_gate([(dZ, SEG_ROW)], Wseg, N, t, gx)         # gradient of the ReLU layer's z directly
+                store.gated.add(GradStore._key(t))
+            elif kind == SEG_ROW:
                 ops.linear_cat([(dZ, SEG_ROW)], Wseg, None, N, residual=res, out=gx)
             else:
                 red = S if kind == SEG_JET else Sm
@@ -354,6 +398,7 @@ def run_backward(model, tape, heads, d_hc, d_hd, d_s=None, scale=None):
     if d_hd is not None:
         store.seed(heads.discrete, d_hd.reshape(-1, d_hd.shape[-1]))
     produced = _produced(tape)
+    store.relu_gates, store.gated = _relu_gates(tape), set()
     mi = next(e[3] if e[0] == "embed" else e[2] for e in tape if e[0] in ("embed", "toyin"))
     seed = model.seed
     n_acc = sum(GW_REPLICAS * (e[1].weight_v.numel() + e[1].weight_v.shape[0] + 8) for e in tape if e[0] == "linear")

@@ -524,3 +524,18 @@ def test_pack_params_matches_torch_split():
         got = torch.zeros(n_main + F * 768, device="cuda")
         fused._fill_packed(got, n_main, flat.cuda(), gather.cuda(), None if g2 is None else g2.cuda(), gather_x.cuda())
         assert torch.equal(got.cpu().view(torch.int32), want.view(torch.int32))
+
+
+@pytest.mark.parametrize("M,K,Nout", [(6000, 64, 256), (300, 128, 256), (5000, 48, 40), (64, 37, 20)])
+def test_linear_cat_gate(ops, M, K, Nout):
+    """mmb_linear_cat_gate = (x W^T) * [gate > 0] on every kernel family of mmb_linear_cat (row streaming, split-K,
+    tiled, generic), against fp64."""
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(Nout, K, generator=g) / K ** 0.5
+    gate = torch.randn(M, Nout, generator=g)
+    gate[::7] = 0.0                                     # relu output exactly 0: no gradient
+    want = torch.nn.functional.linear(x.double(), W.double()) * (gate > 0).double()
+    out = torch.full((M, Nout), 7.0, device="cuda")
+    ops.linear_cat_gate([(dev(x), ops.SEG_ROW)], dev(W), 1, dev(gate), out)
+    close(out.double(), want, rtol=1e-4, atol=2e-5)

@@ -258,14 +258,16 @@ int mmb_linear_cat_ln(int M, int rows_per_jet, int n_seg, const void* const* seg
                       const float* residual, int64_t res_ld, float* Y1, int64_t y1_ld, const float* gamma,
                       const float* beta, float eps, float* Yln, int64_t yln_ld, float* stats, void* stream);
 
-/* Reverse pass of a ReLU layer folded into the GEMM that produces its output gradient (autograd of
- * `linear2(relu(linear1(x)))` in nn.TransformerEncoderLayer, particle_transformer.py:29-50):
- *   Y = ( cat_s[X_s] @ W^T ) * [gate > 0]     gate (M,Nout) = the ReLU layer's output (or pre-activation)
- * i.e. dZ of the ReLU layer straight from dZ of its consumer, without the round trip through mmb_act_bwd. */
+/* Reverse pass of an activation folded into the GEMM that produces the gradient of its output (autograd of
+ * `linear2(relu(linear1(x)))` in nn.TransformerEncoderLayer, particle_transformer.py:29-50; of the SELU / GELU
+ * MLPs of the heads and of the toy model):
+ *   Y = ( cat_s[X_s] @ W^T ) * act'(gate)     gate (M,Nout) = the layer's pre-activation (GELU), anything with its
+ *                                             sign (MMB_ACT_RELU, _LRELU) or its output (MMB_ACT_SELU)
+ * i.e. dZ of the activated layer straight from dZ of its consumer, without the round trip through mmb_act_bwd. */
 int mmb_linear_cat_gate(int M, int rows_per_jet, int n_seg, const void* const* seg_ptr_host,
                         const int* seg_width_host, const int* seg_kind_host, const int* seg_ld_host,
-                        const float* maskf, const float* W, int64_t w_ld, int Nout, const float* gate, int64_t gate_ld,
-                        float* Y, int64_t y_ld, void* stream);
+                        const float* maskf, const float* W, int64_t w_ld, int Nout, int gate_act, const float* gate,
+                        int64_t gate_ld, float* Y, int64_t y_ld, void* stream);
 
 /* EPiCEncoder._meansum_pool (epic.py:100-107) without the concat:
  * pooled[b, 0:H] = sum_n x*mask / counts[b] ; pooled[b, H:2H] = 0.01 * sum_n x*mask. */

@@ -53,10 +53,12 @@ struct Post {
   const float* ln_beta;
   float ln_eps;
   float* ln_stats;
-  // gate of the first stage (mmb_linear_cat_gate: the reverse pass of a ReLU layer folded into the GEMM that
-  // produces its output gradient): v = gate > 0 ? v : 0, applied after the residual
+  // gate of the first stage (mmb_linear_cat_gate: the reverse pass of an activation folded into the GEMM that
+  // produces the gradient of its output): v *= act'(gate), applied after the residual.  gate = the pre-activation
+  // (GELU) or anything with its sign (ReLU, leaky ReLU; SELU: the output itself)
   const float* gate;
   int64_t gate_ld;
+  int gate_act;
 };
 
 // inverted dropout with a Philox keep-mask indexed by the element (row*Nout+col)
@@ -76,6 +78,22 @@ __device__ inline float apply_act(int act, float x) {
     return x > 0.0f ? 1.0507009873554804934193349852946f * x
                     : (1.0507009873554804934193349852946f * 1.6732632423543772848170429916717f) * (expf(x) - 1.0f);
   return x;
+}
+
+// act'(z) from ref: the pre-activation z for GELU; anything with the sign of z for (leaky) ReLU; the OUTPUT y for SELU
+// (y > 0 -> scale, else scale*alpha*exp(z) = y + scale*alpha) -- the same function as backward_kernels.hip: act_grad
+__device__ inline float act_grad(int act, float ref) {
+  if (act == MMB_ACT_GELU) {
+    const float cdf = 0.5f * (1.0f + erff(ref * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * ref * ref);
+    return cdf + ref * pdf;
+  }
+  if (act == MMB_ACT_LRELU) return ref > 0.0f ? 1.0f : 0.01f;
+  if (act == MMB_ACT_RELU) return ref > 0.0f ? 1.0f : 0.0f;
+  if (act == MMB_ACT_SELU)
+    return ref > 0.0f ? 1.0507009873554804934193349852946f
+                      : ref + 1.0507009873554804934193349852946f * 1.6732632423543772848170429916717f;
+  return 1.0f;
 }
 
 // generic element fetch of the concatenated input (slow path only)
@@ -154,7 +172,12 @@ epilogue_stage1(f32x16& v, const TileIO<FULL>& io, int Nout, const float* __rest
   }
   if (post.gate) {
     io.load16(post.gate, post.gate_ld, t);
-    static_for<16>([&](auto ic) { constexpr int i = decltype(ic)::v; v[i] = t[i] > 0.0f ? v[i] : 0.0f; });
+    switch (post.gate_act) {                     // (one uniform switch, as apply_act16)
+      case MMB_ACT_GELU: static_for<16>([&](auto ic) { constexpr int i = decltype(ic)::v; v[i] *= act_grad(MMB_ACT_GELU, t[i]); }); break;
+      case MMB_ACT_LRELU: static_for<16>([&](auto ic) { constexpr int i = decltype(ic)::v; v[i] *= act_grad(MMB_ACT_LRELU, t[i]); }); break;
+      case MMB_ACT_SELU: static_for<16>([&](auto ic) { constexpr int i = decltype(ic)::v; v[i] *= act_grad(MMB_ACT_SELU, t[i]); }); break;
+      default: static_for<16>([&](auto ic) { constexpr int i = decltype(ic)::v; v[i] = t[i] > 0.0f ? v[i] : 0.0f; }); break;
+    }
   }
   if (Y) io.store16(Y, y_ld, v);
 }
@@ -1154,18 +1177,19 @@ extern "C" int mmb_linear_cat(int M, int rows_per_jet, int n_seg, const void* co
   MMB_REQUIRE(Y || Y2, "mmb_linear_cat: no output given");
   MMB_REQUIRE(post_act >= 0 && post_act <= 3, "mmb_linear_cat: bad post activation %d", post_act);   // (SELU: first stage only)
   MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_linear_cat: dropout p=%f outside [0,1)", drop_p);
-  Post post{Y2, y2_ld, res2, res2_ld, post_act, drop_p, seed, offset, nullptr, nullptr, 0.0f, nullptr, nullptr, 0};
+  Post post{Y2, y2_ld, res2, res2_ld, post_act, drop_p, seed, offset, nullptr, nullptr, 0.0f, nullptr, nullptr, 0, MMB_ACT_NONE};
   return linear_cat_impl(M, rows_per_jet, n_seg, seg_ptr, seg_width, seg_kind, seg_ld, maskf, W, w_ld, bias, Nout, act,
                          residual, res_ld, row_scale, Y, y_ld, pre_act, post, nullptr, stream);
 }
 
 extern "C" int mmb_linear_cat_gate(int M, int rows_per_jet, int n_seg, const void* const* seg_ptr,
                                    const int* seg_width, const int* seg_kind, const int* seg_ld, const float* maskf,
-                                   const float* W, int64_t w_ld, int Nout, const float* gate, int64_t gate_ld, float* Y,
-                                   int64_t y_ld, void* stream) {
+                                   const float* W, int64_t w_ld, int Nout, int gate_act, const float* gate,
+                                   int64_t gate_ld, float* Y, int64_t y_ld, void* stream) {
   MMB_REQUIRE(M > 0 && Nout > 0, "mmb_linear_cat_gate: empty shape M=%d Nout=%d", M, Nout);
+  MMB_REQUIRE(gate_act >= 1 && gate_act <= 4, "mmb_linear_cat_gate: bad activation %d", gate_act);
   MMB_REQUIRE(gate && Y && gate_ld >= Nout && y_ld >= Nout, "mmb_linear_cat_gate: NULL gate / output or row stride < Nout");
-  Post post{nullptr, 0, nullptr, 0, MMB_ACT_NONE, 0.0f, 0, 0, nullptr, nullptr, 0.0f, nullptr, gate, gate_ld};
+  Post post{nullptr, 0, nullptr, 0, MMB_ACT_NONE, 0.0f, 0, 0, nullptr, nullptr, 0.0f, nullptr, gate, gate_ld, gate_act};
   return linear_cat_impl(M, rows_per_jet, n_seg, seg_ptr, seg_width, seg_kind, seg_ld, maskf, W, w_ld, nullptr, Nout,
                          MMB_ACT_NONE, nullptr, 0, nullptr, Y, y_ld, nullptr, post, nullptr, stream);
 }
@@ -1178,7 +1202,7 @@ extern "C" int mmb_linear_cat_ln(int M, int rows_per_jet, int n_seg, const void*
   MMB_REQUIRE(M > 0 && Nout > 0, "mmb_linear_cat_ln: empty shape M=%d Nout=%d", M, Nout);
   MMB_REQUIRE(gamma && beta && Yln && yln_ld >= Nout, "mmb_linear_cat_ln: NULL gamma / beta / output");
   MMB_REQUIRE(!Y1 || y1_ld >= Nout, "mmb_linear_cat_ln: y1 row stride < Nout");
-  Post post{Yln, yln_ld, nullptr, 0, MMB_ACT_NONE, 0.0f, 0, 0, gamma, beta, eps, stats, nullptr, 0};
+  Post post{Yln, yln_ld, nullptr, 0, MMB_ACT_NONE, 0.0f, 0, 0, gamma, beta, eps, stats, nullptr, 0, MMB_ACT_NONE};
   bool done = false;
   if (int rc = linear_cat_impl(M, rows_per_jet, n_seg, seg_ptr, seg_width, seg_kind, seg_ld, maskf, W, w_ld, bias, Nout,
                                act, residual, res_ld, nullptr, Y1, y1_ld, nullptr, post, &done, stream))

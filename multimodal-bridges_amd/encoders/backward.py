@@ -29,7 +29,7 @@ GW_REPLICAS = 8
 class GradStore:
     def __init__(self):
         self.bufs = {}
-        self.relu_gates, self.gated = set(), set()      # (see _relu_gates)
+        self.relu_gates, self.gated = {}, set()         # (see _relu_gates)
 
     @staticmethod
     def _key(t):
@@ -132,11 +132,11 @@ def _produced(tape):
 
 
 def _relu_gates(tape):
-    """Keys of ReLU-layer outputs whose reverse pass can be folded into their consumer's input-gradient GEMM
-    (mmb_linear_cat_gate): plain first stage (no residual, no second stage), read exactly once on the tape, and that by
-    a Linear as a per-particle ROW segment."""
+    """{key of an activated layer's output: (act, reference tensor)} for the layers whose reverse pass can be folded
+    into their consumer's input-gradient GEMM (mmb_linear_cat_gate): plain first stage (no residual, no second stage),
+    read exactly once on the tape, and that by a Linear as a per-particle ROW segment."""
     if os.environ.get("MMB_RELU_GATE") == "0":         # A/B switch: mmb_act_bwd for every activation
-        return set()
+        return {}
     k = GradStore._key
     uses, row_uses = {}, {}
 
@@ -157,13 +157,14 @@ def _relu_gates(tape):
         elif e[0] == "cat":
             for part in e[1]:
                 use(part)
-    gates = set()
+    gates = {}
     for e in tape:
-        if e[0] in ("linear", "plinear") and e[4] == "relu" and e[5] is None and e[6] is None and e[10] is None \
-                and e[9] is not None and GradStore._owns_storage(e[9]):
+        if e[0] in ("linear", "plinear") and e[4] in ("relu", "lrelu", "selu", "gelu") and e[5] is None \
+                and e[6] is None and e[10] is None and e[9] is not None and GradStore._owns_storage(e[9]):
+            ref = e[8] if e[4] == "gelu" else e[9]          # GELU' needs the pre-activation, the others y1's sign / value
             key = k(e[9])
-            if uses.get(key, 0) == 1 and row_uses.get(key, 0) == 1:
-                gates.add(key)
+            if ref is not None and uses.get(key, 0) == 1 and row_uses.get(key, 0) == 1:
+                gates[key] = (e[4], ref)
     return gates
 
 
@@ -310,7 +311,8 @@ def _linear_bwd(e, store, produced, mi, seed, arena, touched):
             res = None if fresh else gx
             Wseg = WT[koff:koff + Ks]
             if kind == SEG_ROW and fresh and GradStore._key(t) in store.relu_gates:
-                ops.linear_cat_gate([(dZ, SEG_ROW)], Wseg, N, t, gx)         # gradient of the ReLU layer's z directly
+                g_act, g_ref = store.relu_gates[GradStore._key(t)]
+                ops.linear_cat_gate([(dZ, SEG_ROW)], Wseg, N, g_ref, gx, act=g_act)    # dZ of the activated layer
                 store.gated.add(GradStore._key(t))
             elif kind == SEG_ROW:
                 ops.linear_cat([(dZ, SEG_ROW)], Wseg, None, N, residual=res, out=gx)

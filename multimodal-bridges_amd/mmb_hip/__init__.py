@@ -51,8 +51,8 @@ SIGNATURES = {
                        c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int, C.c_float, C.c_uint64, C.c_uint64, c_f32p,
                        C.c_int64, c_f32p, C.c_int64, c_stream],
     "mmb_linear_cat_gate": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
-                            C.POINTER(C.c_int), c_f32p, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p, C.c_int64,
-                            c_stream],
+                            C.POINTER(C.c_int), c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p,
+                            C.c_int64, c_stream],
     "mmb_linear_cat_ln": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
                           C.POINTER(C.c_int), c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int, C.c_int, c_f32p, C.c_int64,
                           c_f32p, C.c_int64, c_f32p, c_f32p, C.c_float, c_f32p, C.c_int64, c_f32p, c_stream],

@@ -288,9 +288,12 @@ def linear_cat(segs, W, bias, rows_per_jet, maskf=None, act=None, residual=None,
     return res
 
 
-def linear_cat_gate(segs, W, rows_per_jet, gate, out, maskf=None):
-    """out = (cat(segs) @ W^T) * [gate > 0]: the gradient of a ReLU layer's pre-activation from the gradient of its
-    consumer's (one GEMM, no mmb_act_bwd round trip).  gate, out: (M, Nout) float32, unit inner stride."""
+def linear_cat_gate(segs, W, rows_per_jet, gate, out, maskf=None, act="relu"):
+    """out = (cat(segs) @ W^T) * act'(gate): the gradient of an activated layer's pre-activation from the gradient of
+    its consumer's (one GEMM, no mmb_act_bwd round trip).  gate = the pre-activation (gelu), anything with its sign
+    (relu, lrelu) or the output (selu); gate, out: (M, Nout) float32, unit inner stride."""
+    if act not in ("relu", "lrelu", "gelu", "selu"):
+        raise MMBError(f"linear_cat_gate: no derivative for activation {act!r}")
     for t, _ in list(segs) + [(gate, 0), (out, 0), (W, 0)]:
         if t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda or t.dtype != torch.float32:
             raise MMBError("linear_cat_gate: operands must be 2-D float32 HIP tensors with unit inner stride")
@@ -301,7 +304,7 @@ def linear_cat_gate(segs, W, rows_per_jet, gate, out, maskf=None):
     if _m.PROFILE is not None:
         _m.PROFILE_META = {"M": M, "K": sum(widths), "Nout": Nout, "flops": 2.0 * M * sum(widths) * Nout}
     call("mmb_linear_cat_gate", M, rows_per_jet, n, ptrs, widths, kinds, lds, f32(maskf, "maskf"), W.data_ptr(), W.stride(0),
-         Nout, gate.data_ptr(), gate.stride(0), out.data_ptr(), out.stride(0), stream())
+         Nout, ACT[act], gate.data_ptr(), gate.stride(0), out.data_ptr(), out.stride(0), stream())
     _m.PROFILE_META = None
     return out
 

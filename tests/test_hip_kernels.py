@@ -527,15 +527,22 @@ def test_pack_params_matches_torch_split():
 
 
 @pytest.mark.parametrize("M,K,Nout", [(6000, 64, 256), (300, 128, 256), (5000, 48, 40), (64, 37, 20)])
-def test_linear_cat_gate(ops, M, K, Nout):
-    """mmb_linear_cat_gate = (x W^T) * [gate > 0] on every kernel family of mmb_linear_cat (row streaming, split-K,
-    tiled, generic), against fp64."""
+@pytest.mark.parametrize("act", ["relu", "lrelu", "gelu", "selu"])
+def test_linear_cat_gate(ops, M, K, Nout, act):
+    """mmb_linear_cat_gate = (x W^T) * act'(gate) on every kernel family of mmb_linear_cat (row streaming, split-K,
+    tiled, generic), against fp64 autograd of the activation."""
     g = torch.Generator().manual_seed(M + K)
     x = torch.randn(M, K, generator=g)
     W = torch.randn(Nout, K, generator=g) / K ** 0.5
     gate = torch.randn(M, Nout, generator=g)
     gate[::7] = 0.0                                     # relu output exactly 0: no gradient
-    want = torch.nn.functional.linear(x.double(), W.double()) * (gate > 0).double()
+    z = gate.double().requires_grad_(True)
+    fn = {"relu": torch.relu, "lrelu": torch.nn.functional.leaky_relu, "gelu": torch.nn.functional.gelu,
+          "selu": torch.nn.functional.selu}[act]
+    y = fn(z)
+    y.sum().backward()                                  # z.grad = act'(z)
+    ref = y.detach().float() if act == "selu" else gate   # SELU takes its derivative from the OUTPUT
+    want = torch.nn.functional.linear(x.double(), W.double()) * z.grad
     out = torch.full((M, Nout), 7.0, device="cuda")
-    ops.linear_cat_gate([(dev(x), ops.SEG_ROW)], dev(W), 1, dev(gate), out)
+    ops.linear_cat_gate([(dev(x), ops.SEG_ROW)], dev(W), 1, dev(ref), out, act=act)
     close(out.double(), want, rtol=1e-4, atol=2e-5)

@@ -578,7 +578,9 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& h, bf16x8& m, bf1
   l = __builtin_bit_cast(bf16x8, L);
 }
 
-template <int NT, int THREADS, bool SIMPLE>   // SIMPLE: one ROW segment (no segment search, no scale)
+template <int NT, int THREADS, bool SIMPLE, bool LN>   // SIMPLE: one ROW segment (no segment search, no scale);
+                                                       // LN: LayerNorm second stage (its own instantiation: the
+                                                       // row statistics cost registers the plain kernel must not pay)
 __global__ void __launch_bounds__(THREADS)
 linear_stream_x6_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __restrict__ maskf,
                         const float* __restrict__ W, int64_t w_ld, const float* __restrict__ bias, int Nout, int act,
@@ -715,7 +717,7 @@ linear_stream_x6_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __
       consume(bufB, scaleB, 2 * p + 1);
     }
     const int row0 = t * 32;
-    if (post.ln_gamma != nullptr) {             // (the host launches this only with Nout == 32 NT, one column block)
+    if constexpr (LN) {                         // (the host launches this only with Nout == 32 NT, one column block)
       if (row0 + 32 <= M)
         epilogue_rows_ln<NT, true>(acc, row0, col0, r32, half, M, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld,
                                    pre_act, post);
@@ -1130,9 +1132,17 @@ static int linear_cat_impl(int M, int rows_per_jet, int n_seg, const void* const
   } while (0)
       if (x6) {                                  // wider column blocks need more registers: fewer waves per block
         const bool simple = n_seg == 1 && seg_kind[0] == MMB_SEG_ROW;
-        if (snt == 4) { if (simple) MMB_STREAM((linear_stream_x6_kernel<4, 512, true>), 512); else MMB_STREAM((linear_stream_x6_kernel<4, 512, false>), 512); }
-        else if (snt == 2) { if (simple) MMB_STREAM((linear_stream_x6_kernel<2, 768, true>), 768); else MMB_STREAM((linear_stream_x6_kernel<2, 768, false>), 768); }
-        else { if (simple) MMB_STREAM((linear_stream_x6_kernel<1, 768, true>), 768); else MMB_STREAM((linear_stream_x6_kernel<1, 768, false>), 768); }
+#define MMB_X6(NT_, TH_)                                                                               \
+  do {                                                                                                 \
+    if (ln_stream && simple) MMB_STREAM((linear_stream_x6_kernel<NT_, TH_, true, true>), TH_);         \
+    else if (ln_stream) MMB_STREAM((linear_stream_x6_kernel<NT_, TH_, false, true>), TH_);             \
+    else if (simple) MMB_STREAM((linear_stream_x6_kernel<NT_, TH_, true, false>), TH_);                \
+    else MMB_STREAM((linear_stream_x6_kernel<NT_, TH_, false, false>), TH_);                           \
+  } while (0)
+        if (snt == 4) MMB_X6(4, 512);
+        else if (snt == 2) MMB_X6(2, 768);
+        else MMB_X6(1, 768);
+#undef MMB_X6
       } else {
         if (snt == 2) MMB_STREAM((linear_stream_kernel<2>), 1024);
         else MMB_STREAM((linear_stream_kernel<1>), 1024);

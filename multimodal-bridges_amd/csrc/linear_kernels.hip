@@ -132,9 +132,10 @@ __device__ __forceinline__ void apply_act16(int act, f32x16& v) {
 // back and awaited once (the per-element form compiled to ~500 branches and one awaited load per element).
 template <bool FULL>
 struct TileIO {
-  int rbase, nrow, col;                        // rows of this lane's 16 that exist: offsets (i&3) + 8*(i>>2) < nrow
+  int row0, half, nrow, col;                   // rows of this lane's 16 that exist: offsets (i&3) + 8*(i>>2) < nrow
+  __device__ __forceinline__ int rbase() const { return row0 + 4 * half; }
   __device__ __forceinline__ void load16(const float* base, int64_t ld, f32x16& r) const {
-    const float* p = base + (int64_t)rbase * ld + col;
+    const float* p = base + (int64_t)rbase() * ld + col;
     static_for<16>([&](auto ic) {
       constexpr int i = decltype(ic)::v;
       constexpr int off = (i & 3) + 8 * (i >> 2);
@@ -142,7 +143,7 @@ struct TileIO {
     });
   }
   __device__ __forceinline__ void store16(float* base, int64_t ld, const f32x16& r) const {
-    float* p = base + (int64_t)rbase * ld + col;
+    float* p = base + (int64_t)rbase() * ld + col;
     static_for<16>([&](auto ic) {
       constexpr int i = decltype(ic)::v;
       constexpr int off = (i & 3) + 8 * (i >> 2);
@@ -154,12 +155,11 @@ struct TileIO {
 // first stage: v = act(v + bias) + residual [* row_scale] -> Y (and the pre-activation)
 template <bool FULL>
 __device__ __forceinline__ void
-epilogue_stage1(f32x16& v, const TileIO<FULL>& io, int Nout, const float* __restrict__ bias, int act,
+epilogue_stage1(f32x16& v, const TileIO<FULL>& io, int Nout, float bv, int act,
                 const float* __restrict__ residual, int64_t res_ld, const float* __restrict__ row_scale,
                 float* __restrict__ Y, int64_t y_ld, float* __restrict__ pre_act, const Post& post) {
-  f32x16 t;
-  const float bv = bias ? bias[io.col] : 0.0f;
-  static_for<16>([&](auto ic) { v[decltype(ic)::v] += bv; });
+  f32x16 t;                                      // bv: the bias of this lane's column (loaded by the caller: a load here
+  static_for<16>([&](auto ic) { v[decltype(ic)::v] += bv; });   // would wait for every load in flight, prefetches included)
   if (pre_act) io.store16(pre_act, (int64_t)Nout, v);
   apply_act16(act, v);
   if (residual) {
@@ -184,11 +184,11 @@ epilogue_stage1(f32x16& v, const TileIO<FULL>& io, int Nout, const float* __rest
 
 template <bool FULL>
 __device__ __forceinline__ void
-epilogue_tile_body(f32x16 v, int row0, int col, int half, int M, int Nout, const float* __restrict__ bias, int act,
+epilogue_tile_body(f32x16 v, int row0, int col, int half, int M, int Nout, float bv, int act,
                    const float* __restrict__ residual, int64_t res_ld, const float* __restrict__ row_scale,
                    float* __restrict__ Y, int64_t y_ld, float* __restrict__ pre_act, const Post& post) {
-  const TileIO<FULL> io{row0 + 4 * half, M - (row0 + 4 * half), col};
-  epilogue_stage1<FULL>(v, io, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);
+  const TileIO<FULL> io{row0, half, M - (row0 + 4 * half), col};
+  epilogue_stage1<FULL>(v, io, Nout, bv, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);
   if (post.Y2) {
     f32x16 t;
     apply_act16(post.act, v);
@@ -196,7 +196,7 @@ epilogue_tile_body(f32x16 v, int row0, int col, int half, int M, int Nout, const
       static_for<16>([&](auto ic) {
         constexpr int i = decltype(ic)::v;
         v[i] = dropout_apply(v[i], post.drop_p, post.seed, post.offset,
-                             (uint64_t)(io.rbase + (i & 3) + 8 * (i >> 2)) * Nout + col);
+                             (uint64_t)(io.rbase() + (i & 3) + 8 * (i >> 2)) * Nout + col);
       });
     if (post.res2) {
       io.load16(post.res2, post.res2_ld, t);
@@ -206,16 +206,26 @@ epilogue_tile_body(f32x16 v, int row0, int col, int half, int M, int Nout, const
   }
 }
 
+// bv: bias of column col, already in a register
+__device__ __forceinline__ void epilogue_tile_b(const f32x16& v, int row0, int col, int half, int M, int Nout, float bv,
+                                                int act, const float* __restrict__ residual, int64_t res_ld,
+                                                const float* __restrict__ row_scale, float* __restrict__ Y,
+                                                int64_t y_ld, float* __restrict__ pre_act, const Post& post) {
+  if (col >= Nout) return;
+  row0 = __builtin_amdgcn_readfirstlane(row0);   // (wave-uniform at every caller: a tile belongs to one wave)
+  if (row0 + 32 <= M)
+    epilogue_tile_body<true>(v, row0, col, half, M, Nout, bv, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);
+  else
+    epilogue_tile_body<false>(v, row0, col, half, M, Nout, bv, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);
+}
 __device__ __forceinline__ void epilogue_tile(const f32x16& v, int row0, int col, int half, int M, int Nout,
                                               const float* __restrict__ bias, int act,
                                               const float* __restrict__ residual, int64_t res_ld,
                                               const float* __restrict__ row_scale, float* __restrict__ Y,
                                               int64_t y_ld, float* __restrict__ pre_act, const Post& post) {
   if (col >= Nout) return;
-  if (row0 + 32 <= M)
-    epilogue_tile_body<true>(v, row0, col, half, M, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);
-  else
-    epilogue_tile_body<false>(v, row0, col, half, M, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);
+  epilogue_tile_b(v, row0, col, half, M, Nout, bias ? bias[col] : 0.0f, act, residual, res_ld, row_scale, Y, y_ld,
+                  pre_act, post);
 }
 
 // The wave owns WHOLE rows (Nout = 32 NT): first stage of every tile, then LayerNorm over the row -- a row lives in
@@ -239,13 +249,13 @@ __device__ __forceinline__ float half_sum32(float s) {
 template <int NT, bool FULL>
 __device__ __forceinline__ void
 epilogue_rows_ln(f32x16 (&v)[NT], int row0, int col0, int r32, int half, int M, int Nout,
-                 const float* __restrict__ bias, int act, const float* __restrict__ residual, int64_t res_ld,
+                 const float (&bvj)[NT], int act, const float* __restrict__ residual, int64_t res_ld,
                  const float* __restrict__ row_scale, float* __restrict__ Y, int64_t y_ld,
                  float* __restrict__ pre_act, const Post& post) {
   static_for<NT>([&](auto jc) {
     constexpr int j = decltype(jc)::v;
-    const TileIO<FULL> io{row0 + 4 * half, M - (row0 + 4 * half), col0 + 32 * j + r32};
-    epilogue_stage1<FULL>(v[j], io, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);
+    const TileIO<FULL> io{row0, half, M - (row0 + 4 * half), col0 + 32 * j + r32};
+    epilogue_stage1<FULL>(v[j], io, Nout, bvj[j], act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);
   });
   const float inv_n = 1.0f / (float)(32 * NT);
   f32x16 mean, rstd;
@@ -266,7 +276,7 @@ epilogue_rows_ln(f32x16 (&v)[NT], int row0, int col0, int r32, int half, int M, 
   static_for<NT>([&](auto jc) {
     constexpr int j = decltype(jc)::v;
     const int col = col0 + 32 * j + r32;
-    const TileIO<FULL> io{row0 + 4 * half, M - (row0 + 4 * half), col};
+    const TileIO<FULL> io{row0, half, M - (row0 + 4 * half), col};
     const float gm = post.ln_gamma[col], bt = post.ln_beta[col];
     static_for<16>([&](auto ic) { constexpr int i = decltype(ic)::v; v[j][i] = fmaf(v[j][i] * rstd[i], gm, bt); });
     io.store16(post.Y2, post.y2_ld, v[j]);
@@ -705,6 +715,12 @@ linear_stream_x6_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __
     }
   };
 
+  float bvj[NT];                                // this lane's bias per column tile: loaded ONCE, before the stream
+  static_for<NT>([&](auto jc) {
+    constexpr int j = decltype(jc)::v;
+    const int c = col0 + j * 32 + r32;
+    bvj[j] = (bias != nullptr && c < Nout) ? bias[c] : 0.0f;
+  });
   float bufA[HALF], bufB[HALF];
   float scaleA = 1.0f, scaleB = 1.0f;
   setup(t);
@@ -716,19 +732,19 @@ linear_stream_x6_kernel(int M, int rows_per_jet, Segs sg, int K, const float* __
       consume(bufA, scaleA, 2 * p);
       consume(bufB, scaleB, 2 * p + 1);
     }
-    const int row0 = t * 32;
+    const int row0 = __builtin_amdgcn_readfirstlane(t) * 32;
     if constexpr (LN) {                         // (the host launches this only with Nout == 32 NT, one column block)
       if (row0 + 32 <= M)
-        epilogue_rows_ln<NT, true>(acc, row0, col0, r32, half, M, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld,
+        epilogue_rows_ln<NT, true>(acc, row0, col0, r32, half, M, Nout, bvj, act, residual, res_ld, row_scale, Y, y_ld,
                                    pre_act, post);
       else
-        epilogue_rows_ln<NT, false>(acc, row0, col0, r32, half, M, Nout, bias, act, residual, res_ld, row_scale, Y, y_ld,
+        epilogue_rows_ln<NT, false>(acc, row0, col0, r32, half, M, Nout, bvj, act, residual, res_ld, row_scale, Y, y_ld,
                                     pre_act, post);
     } else {
       static_for<NT>([&](auto jc) {
         constexpr int j = decltype(jc)::v;
-        epilogue_tile(acc[j], row0, col0 + j * 32 + r32, half, M, Nout, bias, act, residual, res_ld, row_scale, Y,
-                      y_ld, pre_act, post);
+        epilogue_tile_b(acc[j], row0, col0 + j * 32 + r32, half, M, Nout, bvj[j], act, residual, res_ld, row_scale, Y,
+                        y_ld, pre_act, post);
       });
     }
   }

@@ -120,10 +120,20 @@ int mmb_jet_observables(int B, int N, int Dc, const float* x, const int64_t* k, 
 
 /* Generation post-processing, in place (pipeline/callbacks_generator.py:99-128 + TensorMultiModal.apply_mask,
  * tensorclass.py:96-106): x = x*scale[d] + shift[d] (scale/shift of length Dc, both NULL for no transform:
- * "standardize" -> std/mean, "normalize" -> (max-min)/min), log_pt != 0 additionally x[...,0] = exp(x[...,0]) - 1e-6;
- * then x *= mask and k = (k*mask).long().  x (P,Dc) | NULL, k (P) | NULL, maskf (P) f32. */
-int mmb_postprocess(int64_t P, int Dc, float* x, int64_t* k, const float* maskf, const float* scale,
+ * "standardize" -> std/mean, "normalize" -> (max-min)/min); log_pt (:112-116) additionally exp(.) - 1e-6 on what the
+ * reference's `paths.continuous[:, :, 0]` selects: log_pt = 1 feature 0 of every particle (a (J,N,Dc) sample),
+ * log_pt = 2 every feature of slot 0 of every jet (the same expression on the stacked (T,J,N,Dc) paths that the
+ * callback really passes, :69); then x *= mask and k = (k*mask).long().  x (P,Dc) | NULL, k (P) | NULL, maskf (P) f32,
+ * N particles per jet (P a multiple of N). */
+int mmb_postprocess(int64_t P, int N, int Dc, float* x, int64_t* k, const float* maskf, const float* scale,
                     const float* shift, int log_pt, void* stream);
+
+/* The "onehot" branch of the same function (callbacks_generator.py:118-125): the last V of the D continuous channels
+ * carry token scores.  Inverse transform of all D channels (scale/shift of length D), k = argmax of the last V (first
+ * maximum), x = the first D - V channels (xout NULL when D == V: the reference deletes the continuous mode), then
+ * apply_mask.  xin (P,D) -> xout (P,D-V), kout (P). */
+int mmb_postprocess_onehot(int64_t P, int N, int D, int V, const float* xin, float* xout, int64_t* kout,
+                           const float* maskf, const float* scale, const float* shift, int log_pt, void* stream);
 
 /* ---------------------------------------------------------------- K-B continuous solver */
 

@@ -435,6 +435,9 @@ __device__ __forceinline__ void mma_x(f32x16 (&acc)[OT], TileFn&& tile, WRsrc R,
         if constexpr (g + D < NG)
           ffor<3>([&](auto pc) { constexpr int pl = decltype(pc)::v;
             ring[(g + D) % (D + 1)].p[pl] = wload(R, woff, ((g + D) * 3 + pl) * 64, lane16); });
+#ifdef MMB_PIN
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         const bf16x8 ah = __builtin_bit_cast(bf16x8, ring[cur].p[0]), am = __builtin_bit_cast(bf16x8, ring[cur].p[1]),
                      al = __builtin_bit_cast(bf16x8, ring[cur].p[2]);
         acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[ot], 0, 0, 0);

@@ -210,25 +210,53 @@ static int launch_jump(const char* name, int B, int N, int V, const float* logit
 
 // ------------------------------------------------------------------ post-processing ----
 // Generation post-processing (pipeline/callbacks_generator.py:99-128): inverse of the data
-// transform -- x*scale + shift per feature, for "log_pt" additionally x[0] = exp(x[0]) - 1e-6 --
-// followed by TensorMultiModal.apply_mask (tensorclass.py:96-106): x *= mask, k = (k*mask).long().
-// One lane per particle, in place; 2*(4 Dc + 8) + 4 B/particle.
+// transform -- x*scale + shift per feature, for "log_pt" additionally exp(.) - 1e-6 on what the reference's
+// `paths.continuous[:, :, 0]` selects -- followed by TensorMultiModal.apply_mask (tensorclass.py:96-106):
+// x *= mask, k = (k*mask).long().  One lane per particle, in place; 2*(4 Dc + 8) + 4 B/particle.
+// log_pt: 0 off; 1 feature 0 of every particle (a (J,N,Dc) sample); 2 EVERY feature of slot 0 of every jet -- what the
+// same index expression selects on the stacked (T,J,N,Dc) paths the reference's callback hands over (:69,:116).
+__device__ __forceinline__ float post_value(float v, int d, bool slot0, const float* scale, const float* shift,
+                                            int log_pt) {
+  if (scale != nullptr) v = v * scale[d] + shift[d];
+  if ((log_pt == 1 && d == 0) || (log_pt == 2 && slot0)) v = expf(v) - 1e-6f;
+  return v;
+}
+
 __global__ void __launch_bounds__(256)
-postprocess_kernel(int64_t P, int Dc, float* __restrict__ x, int64_t* __restrict__ k,
+postprocess_kernel(int64_t P, int N, int Dc, float* __restrict__ x, int64_t* __restrict__ k,
                    const float* __restrict__ maskf, const float* __restrict__ scale,
                    const float* __restrict__ shift, int log_pt) {
   for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
     const float m = maskf[p];
+    const bool slot0 = (p % N) == 0;
     if (x != nullptr) {
       float* xp = x + p * Dc;
-      for (int d = 0; d < Dc; ++d) {
-        float v = xp[d];
-        if (scale != nullptr) v = v * scale[d] + shift[d];
-        if (log_pt && d == 0) v = expf(v) - 1e-6f;
-        xp[d] = v * m;
-      }
+      for (int d = 0; d < Dc; ++d) xp[d] = post_value(xp[d], d, slot0, scale, shift, log_pt) * m;
     }
     if (k != nullptr) k[p] = (int64_t)((float)k[p] * m);           // (discrete * mask).long(): truncation toward zero
+  }
+}
+
+// "onehot" samples (callbacks_generator.py:118-125): the last V of the D = Dc + V continuous channels carry the token
+// scores.  After the inverse transform of ALL D channels: k = argmax of the last V (first maximum, like
+// torch.argmax), x = the first Dc channels (none when Dc = 0), then apply_mask.  Out of place: (P,D) -> (P,Dc), (P).
+__global__ void __launch_bounds__(256)
+postprocess_onehot_kernel(int64_t P, int N, int D, int V, const float* __restrict__ xin, float* __restrict__ xout,
+                          int64_t* __restrict__ kout, const float* __restrict__ maskf,
+                          const float* __restrict__ scale, const float* __restrict__ shift, int log_pt) {
+  const int Dc = D - V;
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+    const float m = maskf[p];
+    const bool slot0 = (p % N) == 0;
+    const float* xp = xin + p * D;
+    for (int d = 0; d < Dc; ++d) xout[p * Dc + d] = post_value(xp[d], d, slot0, scale, shift, log_pt) * m;
+    int best = 0;
+    float bv = post_value(xp[Dc], Dc, slot0, scale, shift, log_pt);
+    for (int v = 1; v < V; ++v) {
+      const float c = post_value(xp[Dc + v], Dc + v, slot0, scale, shift, log_pt);
+      if (c > bv || (c != c && bv == bv)) { bv = c; best = v; }     // torch.argmax treats NaN as the maximum
+    }
+    kout[p] = (int64_t)((float)best * m);
   }
 }
 
@@ -236,16 +264,32 @@ postprocess_kernel(int64_t P, int Dc, float* __restrict__ x, int64_t* __restrict
 
 using namespace mmb;
 
-extern "C" int mmb_postprocess(int64_t P, int Dc, float* x, int64_t* k, const float* maskf, const float* scale,
+extern "C" int mmb_postprocess(int64_t P, int N, int Dc, float* x, int64_t* k, const float* maskf, const float* scale,
                                const float* shift, int log_pt, void* stream) {
-  MMB_REQUIRE(P > 0, "mmb_postprocess: empty batch");
+  MMB_REQUIRE(P > 0 && N > 0, "mmb_postprocess: empty batch (P=%lld N=%d)", (long long)P, N);
   MMB_REQUIRE(maskf && (x || k), "mmb_postprocess: NULL argument");
   if (x) MMB_REQUIRE(Dc > 0, "mmb_postprocess: Dc=%d", Dc);
   MMB_REQUIRE((scale == nullptr) == (shift == nullptr), "mmb_postprocess: scale and shift go together");
+  MMB_REQUIRE(log_pt >= 0 && log_pt <= 2, "mmb_postprocess: log_pt=%d", log_pt);
   if (log_pt) MMB_REQUIRE(scale, "mmb_postprocess: log_pt needs the standardisation statistics");
-  hipLaunchKernelGGL(postprocess_kernel, dim3(stream_grid(P, 256)), dim3(256), 0, as_stream(stream), P, Dc, x, k,
+  hipLaunchKernelGGL(postprocess_kernel, dim3(stream_grid(P, 256)), dim3(256), 0, as_stream(stream), P, N, Dc, x, k,
                      maskf, scale, shift, log_pt);
   return check_launch("mmb_postprocess");
+}
+
+extern "C" int mmb_postprocess_onehot(int64_t P, int N, int D, int V, const float* xin, float* xout, int64_t* kout,
+                                      const float* maskf, const float* scale, const float* shift, int log_pt,
+                                      void* stream) {
+  MMB_REQUIRE(P > 0 && N > 0, "mmb_postprocess_onehot: empty batch (P=%lld N=%d)", (long long)P, N);
+  MMB_REQUIRE(V > 0 && D >= V, "mmb_postprocess_onehot: D=%d channels cannot hold V=%d token scores", D, V);
+  MMB_REQUIRE(xin && kout && maskf, "mmb_postprocess_onehot: NULL argument");
+  MMB_REQUIRE((D == V) || xout, "mmb_postprocess_onehot: xout is NULL but D - V = %d continuous channels remain", D - V);
+  MMB_REQUIRE((scale == nullptr) == (shift == nullptr), "mmb_postprocess_onehot: scale and shift go together");
+  MMB_REQUIRE(log_pt >= 0 && log_pt <= 2, "mmb_postprocess_onehot: log_pt=%d", log_pt);
+  if (log_pt) MMB_REQUIRE(scale, "mmb_postprocess_onehot: log_pt needs the standardisation statistics");
+  hipLaunchKernelGGL(postprocess_onehot_kernel, dim3(stream_grid(P, 256)), dim3(256), 0, as_stream(stream), P, N, D, V,
+                     xin, xout, kout, maskf, scale, shift, log_pt);
+  return check_launch("mmb_postprocess_onehot");
 }
 
 extern "C" int mmb_euler_step(int64_t n, float* x, const float* v, float dt, void* stream) {

@@ -89,7 +89,9 @@ SIGNATURES = {
                                 C.c_int, C.c_float, c_f32p, C.c_uint64, C.c_uint64, C.c_int, C.c_float, c_f32p,
                                 c_stream],
     "mmb_jet_observables": [C.c_int, C.c_int, C.c_int, c_f32p, c_i64p, c_f32p, c_f32p, c_stream],
-    "mmb_postprocess": [C.c_int64, C.c_int, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, C.c_int, c_stream],
+    "mmb_postprocess": [C.c_int64, C.c_int, C.c_int, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, C.c_int, c_stream],
+    "mmb_postprocess_onehot": [C.c_int64, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p,
+                               C.c_int, c_stream],
     "mmb_grad_weight_rows": [C.c_int, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p,
                              C.c_int, C.c_int64, C.c_int64, c_stream],
     "mmb_weight_norm_bwd_rep": [C.c_int, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int64, c_f32p,

@@ -455,12 +455,27 @@ def weight_norm_bwd_rep(row_off, row_len, v_flat, g_flat, inv, dW_rep, db_rep, o
     return dv, dg, db
 
 
-def postprocess_(x, k, maskf, scale=None, shift=None, log_pt=False):
-    """In-place inverse data transform + apply_mask on a generated sample (x (..,Dc) | None, k (..,1) | None)."""
+def postprocess_(x, k, maskf, scale=None, shift=None, log_pt=0, N=None):
+    """In-place inverse data transform + apply_mask on a generated sample (x (..,N,Dc) | None, k (..,N,1) | None).
+    log_pt: 0 | 1 (feature 0) | 2 (slot 0 of every jet: the reference's index expression on stacked 4-D paths)."""
     P = maskf.numel()
     Dc = x.shape[-1] if x is not None else 0
-    call("mmb_postprocess", P, Dc, f32(x, "x"), i64(k, "k"), f32(maskf, "maskf"), f32(scale, "scale"),
-         f32(shift, "shift"), int(bool(log_pt)), stream())
+    if N is None:
+        N = (x if x is not None else k).shape[-2]
+    call("mmb_postprocess", P, int(N), Dc, f32(x, "x"), i64(k, "k"), f32(maskf, "maskf"), f32(scale, "scale"),
+         f32(shift, "shift"), int(log_pt), stream())
+
+
+def postprocess_onehot(x, V, maskf, scale=None, shift=None, log_pt=0):
+    """'onehot' samples: x (..,N,Dc+V) -> (x (..,N,Dc) | None, k (..,N,1) int64) after the inverse transform, argmax
+    over the last V channels and apply_mask."""
+    P, D, N = maskf.numel(), x.shape[-1], x.shape[-2]
+    Dc = D - V
+    xout = torch.empty(*x.shape[:-1], Dc, dtype=torch.float32, device=x.device) if Dc > 0 else None
+    kout = torch.empty(*x.shape[:-1], 1, dtype=torch.int64, device=x.device)
+    call("mmb_postprocess_onehot", P, int(N), D, int(V), f32(x, "x"), f32(xout, "xout"), i64(kout, "kout"),
+         f32(maskf, "maskf"), f32(scale, "scale"), f32(shift, "shift"), int(log_pt), stream())
+    return xout, kout
 
 
 # ---- multi-problem launches (device tables of 8-byte fields, built once per training workspace) ----

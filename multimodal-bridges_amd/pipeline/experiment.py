@@ -299,7 +299,11 @@ class ExperimentPipeline:
         gen = TensorMultiModal.cat(outs, dim=0)
         if postprocess:
             from pipeline.postprocess import postprocess as _post
-            gen = _post(gen, transform, metadata, getattr(self.config.data, "discrete_features", "tokens"))
+            # the final state (J,N,.) goes in: for "log_pt" that exponentiates feature 0 of every particle; upstream
+            # hands the stacked 4-D paths over, where the same index expression hits slot 0 of every jet instead
+            # (pipeline/postprocess.py reproduces either, by the rank of its input)
+            gen = _post(gen, transform, metadata, getattr(self.config.data, "discrete_features", "tokens"),
+                        getattr(self.config.data, "vocab_size", None))
         if gather and self.dist is not None:
             gen = gather_generated(gen, self.dist, self.rank, self.world)
         if self.rank == 0 and gen is not None and self.experiment_path:

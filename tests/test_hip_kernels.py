@@ -354,26 +354,44 @@ def test_grad_weight_rows(ops, M, K, Nout, x_pad, gw_path, monkeypatch):
     assert float((wide[:, :2] - 0.25).abs().max()) == 0.0 and float((wide[:, 2 + K:] - 0.25).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("transform", [None, "standardize", "normalize", "log_pt"])
-def test_postprocess(ops, transform):
-    """Device post-processing against the CPU restatement of the reference's _postprocess + apply_mask."""
-    from oracle.postprocess import postprocess as ref_post
+POST_CASES = [(tag, rank, tr) for tag in ("tokens3", "onehot11", "onehot8") for rank in (3, 4)
+              for tr in ("none", "standardize", "normalize", "log_pt")]
+
+
+@pytest.mark.parametrize("tag,rank,tr", POST_CASES)
+def test_postprocess(ops, tag, rank, tr):
+    """Device post-processing against the reference's own _postprocess outputs (tests/golden/postprocess.npz:
+    callbacks_generator.py:99-128 run on synthetic samples) -- four transforms, (J,N,D) and stacked (T,J,N,D) input
+    (upstream's `[:, :, 0]` quirk), tokens and both onehot shapes: tokens bit-exact, x rtol 1e-6."""
+    import json
+    from conftest import load_npz
+    from pipeline.postprocess import postprocess
+    from tensorclass import TensorMultiModal
+    z = load_npz("postprocess")
+    stats = json.loads(str(z[f"{tag}:stats_json"]))
+    feats = "onehot" if tag.startswith("onehot") else "tokens"
+    x = torch.from_numpy(z[f"{tag}:r{rank}:x"])
+    k = torch.from_numpy(z[f"{tag}:r{rank}:k"]) if feats == "tokens" else None
+    mask = torch.from_numpy(z[f"{tag}:r{rank}:mask"])
+    paths = TensorMultiModal(None, dev(x), None if k is None else dev(k), dev(mask))
+    out = postprocess(paths, None if tr == "none" else tr, {"target": stats}, feats, 8)
+    key = f"{tag}:r{rank}:{tr}:continuous"
+    if key in z:
+        close(out.continuous, torch.from_numpy(z[key]), rtol=1e-6, atol=1e-6)
+    else:
+        assert out.continuous is None
+    want_k = torch.from_numpy(z[f"{tag}:r{rank}:{tr}:discrete"])
+    assert out.discrete.dtype == torch.int64 and torch.equal(out.discrete.cpu(), want_k)
+
+
+def test_postprocess_discrete_only(ops):
     from pipeline.postprocess import postprocess
     from tensorclass import TensorMultiModal
     g = torch.Generator().manual_seed(5)
-    B, N = 37, 50
-    x = torch.randn(B, N, 3, generator=g)
-    k = torch.randint(0, 8, (B, N, 1), generator=g)
-    mask = (torch.rand(B, N, 1, generator=g) > 0.4).long()
-    stats = {"mean": [1.5, -0.2, 0.1], "std": [0.7, 0.3, 0.25], "min": [-3.0, -1.0, -1.2], "max": [4.0, 1.1, 0.9]}
-    want_x, want_k = ref_post(x, k, mask, transform, stats)
-    paths = TensorMultiModal(None, dev(x), dev(k), dev(mask))
-    out = postprocess(paths, transform, {"target": stats})
-    close(out.continuous, want_x, rtol=1e-5, atol=1e-6)
-    assert torch.equal(out.discrete.cpu(), want_k) and out.discrete.dtype == torch.int64
-    # discrete-only sample
-    out2 = postprocess(TensorMultiModal(None, None, dev(k), dev(mask)), None, None)
-    assert torch.equal(out2.discrete.cpu(), want_k)
+    k = torch.randint(0, 8, (37, 50, 1), generator=g)
+    mask = (torch.rand(37, 50, 1, generator=g) > 0.4).long()
+    out = postprocess(TensorMultiModal(None, None, dev(k), dev(mask)), None, None)
+    assert torch.equal(out.discrete.cpu(), (k * mask).long())
 
 
 def test_grad_weight_rows_multi(ops):

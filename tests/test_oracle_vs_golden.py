@@ -202,3 +202,32 @@ def test_generation(golden, name):
         kf, kr = out["discrete"], t[tag + ":final_k"]
         agree = (kf == kr).float().mean().item()
         assert agree == 1.0, f"{name}/{tag}: final-k agreement {agree}"
+
+
+# ---- _postprocess (pipeline/callbacks_generator.py:99-128) -------------------------------------------
+POST_CASES = [(tag, rank, tr) for tag in ("tokens3", "onehot11", "onehot8") for rank in (3, 4)
+              for tr in ("none", "standardize", "normalize", "log_pt")]
+
+
+@pytest.mark.parametrize("tag,rank,tr", POST_CASES)
+def test_postprocess_restatement_matches_reference(tag, rank, tr):
+    """oracle/postprocess.py against the outputs of the reference's own JetGeneratorCallback._postprocess: the four
+    transforms, a (J,N,D) sample and stacked (T,J,N,D) paths (where upstream's `[:, :, 0]` hits slot 0 of every jet),
+    tokens and the onehot branch with and without remaining continuous channels."""
+    import json
+    from conftest import load_npz
+    from oracle.postprocess import postprocess
+    z = load_npz("postprocess")
+    stats = json.loads(str(z[f"{tag}:stats_json"]))
+    feats = "onehot" if tag.startswith("onehot") else "tokens"
+    x = torch.from_numpy(z[f"{tag}:r{rank}:x"])
+    k = torch.from_numpy(z[f"{tag}:r{rank}:k"]) if feats == "tokens" else None
+    mask = torch.from_numpy(z[f"{tag}:r{rank}:mask"])
+    gx, gk = postprocess(x, k, mask, None if tr == "none" else tr, stats, feats, 8)
+    key = f"{tag}:r{rank}:{tr}:continuous"
+    if key in z:
+        torch.testing.assert_close(gx, torch.from_numpy(z[key]), rtol=0, atol=0)
+    else:
+        assert gx is None and tag == "onehot8"
+    want_k = torch.from_numpy(z[f"{tag}:r{rank}:{tr}:discrete"])
+    assert gk.dtype == torch.int64 and torch.equal(gk, want_k)

@@ -648,6 +648,64 @@ def golden_aoj():
     npz_save("aoj", **out)
 
 
+def golden_postprocess():
+    """the reference's own JetGeneratorCallback._postprocess (pipeline/callbacks_generator.py:99-128) on
+    synthetic samples: the four transforms x {(J,N,D) sample, stacked (T,J,N,D) paths} x {tokens, onehot (Dc = 3 and
+    Dc = 0)}.  The module imports Lightning's Callback / rank_zero_only, pandas, matplotlib and datamodules.utils
+    (fastjet, awkward, vector: absent); the method touches none of them, so the harness registers empty stand-ins
+    for the absent ones (here, never in the reference) before the import."""
+    import tempfile
+    print("[postprocess]")
+    cb = types.ModuleType("lightning.pytorch.callbacks")
+    cb.Callback = object
+    ut = types.ModuleType("lightning.pytorch.utilities")
+    ut.rank_zero_only = lambda f: f
+    sys.modules["lightning.pytorch.callbacks"] = cb
+    sys.modules["lightning.pytorch.utilities"] = ut
+    sys.modules["lightning.pytorch"].callbacks = cb
+    sys.modules["lightning.pytorch"].utilities = ut
+    du = types.ModuleType("datamodules.utils")
+    du.JetFeatures = object
+    import datamodules
+    had = sys.modules.get("datamodules.utils")
+    sys.modules["datamodules.utils"] = du
+    try:
+        from pipeline.callbacks_generator import JetGeneratorCallback
+    finally:
+        if had is not None:
+            sys.modules["datamodules.utils"] = had
+        else:
+            del sys.modules["datamodules.utils"]
+    from tensorclass import TensorMultiModal
+    g = torch.Generator().manual_seed(41)
+    J, N, V = 7, 9, 8
+    out = {}
+    for D, feats in ((3, "tokens"), (3 + V, "onehot"), (V, "onehot")):
+        stats = {"mean": (torch.randn(D, generator=g) * 0.5).tolist(), "std": (torch.rand(D, generator=g) + 0.3).tolist(),
+                 "min": (-1.0 - torch.rand(D, generator=g)).tolist(), "max": (1.0 + torch.rand(D, generator=g)).tolist()}
+        tag = f"{feats}{D}"
+        out[f"{tag}:stats_json"] = json.dumps(stats)
+        for rank in (3, 4):
+            shape = (J, N) if rank == 3 else (2, J, N)
+            x = torch.randn(*shape, D, generator=g)
+            k = torch.randint(0, V, (*shape, 1), generator=g)
+            mask = (torch.rand(*shape, 1, generator=g) > 0.35).long()
+            out[f"{tag}:r{rank}:x"], out[f"{tag}:r{rank}:k"], out[f"{tag}:r{rank}:mask"] = x, k, mask
+            for tr in ("none", "standardize", "normalize", "log_pt"):
+                with tempfile.TemporaryDirectory() as tmp:
+                    with open(os.path.join(tmp, "metadata.json"), "w") as fh:
+                        json.dump({"target": stats}, fh)
+                    cfg = types.SimpleNamespace(path=tmp, data=types.SimpleNamespace(
+                        transform=None if tr == "none" else tr, discrete_features=feats, vocab_size=V))
+                    obj = JetGeneratorCallback(cfg)
+                    paths = TensorMultiModal(None, x.clone(), k.clone() if feats == "tokens" else None, mask.clone())
+                    res = obj._postprocess(paths, transform=cfg.data.transform)
+                if res.continuous is not None:
+                    out[f"{tag}:r{rank}:{tr}:continuous"] = res.continuous
+                out[f"{tag}:r{rank}:{tr}:discrete"] = res.discrete
+    npz_save("postprocess", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
@@ -676,6 +734,7 @@ def main():
     golden_model("S4", V["S4"], 2, 150, "random_full", False, seed=13, steps_list=(5,), explicit_source=True)
     golden_toy()
     golden_aoj()
+    golden_postprocess()
 
 
 if __name__ == "__main__":
@@ -686,5 +745,8 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "aoj":
         _install_stubs()
         golden_aoj()
+    elif len(sys.argv) > 1 and sys.argv[1] == "postprocess":
+        _install_stubs()
+        golden_postprocess()
     else:
         main()

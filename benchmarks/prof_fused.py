@@ -15,7 +15,7 @@ import mmb_hip  # noqa: E402
 import bench  # noqa: E402
 
 NAMES = ["embed", "pool", "glob1", "glob2", "dvec", "loc1_mma", "loc2_mma", "epilogue", "output_mma", "proj_mma",
-         "heads", "step_solver"]
+         "heads", "step_solver", "x1_issue", "x2_poolpart", "x3_combine"]
 
 
 def main():

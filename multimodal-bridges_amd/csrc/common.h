@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "../../include/mmb_hip.h"
 
 namespace mmb {
@@ -29,6 +30,24 @@ inline int check_launch(const char* what) {
 }
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is kept PER DEVICE by the runtime: a process that drives several GPUs
+// must raise the limit on each of them.  One flag per (call site, device), set after the call succeeded; two threads
+// racing on the first call both make the (idempotent) call.  Returns false when the runtime refuses.
+constexpr int kMaxDevices = 64;
+struct PerDeviceOnce {
+  std::atomic<bool> done[kMaxDevices];
+  template <typename F>
+  bool run(F&& f) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return false;
+    if (dev >= kMaxDevices) return f();                       // beyond the table: every call pays the (cheap) set
+    if (done[dev].load(std::memory_order_acquire)) return true;
+    if (!f()) return false;
+    done[dev].store(true, std::memory_order_release);
+    return true;
+  }
+};
 
 // grid for a memory-bound grid-stride kernel: enough blocks to fill 256 CUs x 8, capped
 inline int stream_grid(int64_t work_items, int block) {

@@ -18,6 +18,14 @@ __device__ __forceinline__ void ffor(F&& f) { ffor_impl(f, std::make_integer_seq
 
 constexpr int FE_THREADS = 256;
 
+// A value the optimiser cannot see through: everything derived from it is computed where it is used instead of being
+// hoisted out of the grid-point loop and kept -- i.e. spilled -- across the whole kernel (lane offsets of every matvec
+// shape, LDS addresses: 40 registers of them were going to scratch and coming back behind vmcnt(0) waits).
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 
 // ------------------------------------------------------------------ small helpers ------
 template <int CTRL>
@@ -76,17 +84,19 @@ struct LDesc {
   int b;    // bias [O] (padded to a multiple of 32 for per-particle layers)
 };
 
+constexpr int MAX_DESC = 96;        // layer descriptors cached in LDS (S3: 59, S2: 45)
 struct alignas(16) Lds {
   float temb[128];
   float gcur[64], gskip[64], gnew[64], gcat[64];
   float partial[4 * 128];
   float gh[128];
-  float cvec[128], dvec[128];
+  float cvec[128], dvec[128], bvec[128];   // per-layer time vector, global-vector part + bias, second bias
+  float pooled[400];                // [mean | 0.01 sum | tail]: the input of fc_glob1 / mlp_global.0 (MV::vidx layout)
   float cw[32 * 4], cb[32];       // continuous embedding weight [Ec][Dc<=4], bias
   float table[8 * 32];            // discrete embedding table [V<=8][Ed<=32]
   float cnt;
   int red[4];
-  float park[4][FE_THREADS];      // generation loop: x (3) and k of this lane's particle while a forward runs
+  LDesc desc[MAX_DESC];
 #ifdef MMB_FE_PROF
   unsigned long long tlast;
 #endif
@@ -435,9 +445,6 @@ __device__ __forceinline__ void mma_x(f32x16 (&acc)[OT], TileFn&& tile, WRsrc R,
         if constexpr (g + D < NG)
           ffor<3>([&](auto pc) { constexpr int pl = decltype(pc)::v;
             ring[(g + D) % (D + 1)].p[pl] = wload(R, woff, ((g + D) * 3 + pl) * 64, lane16); });
-#ifdef MMB_PIN
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         const bf16x8 ah = __builtin_bit_cast(bf16x8, ring[cur].p[0]), am = __builtin_bit_cast(bf16x8, ring[cur].p[1]),
                      al = __builtin_bit_cast(bf16x8, ring[cur].p[2]);
         acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[ot], 0, 0, 0);
@@ -448,6 +455,227 @@ __device__ __forceinline__ void mma_x(f32x16 (&acc)[OT], TileFn&& tile, WRsrc R,
         acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[ot], 0, 0, 0);
       });
     });
+  });
+}
+
+// ---- forward kernels, round 3: ONE weight-fragment stream per forward ----------------------------------------
+// The ring holds the next RD fragments of the stream at all times: step g of a GEMM consumes slot g % RD and refills
+// it at once with fragment g + RD -- of the same matrix, or (the last RD steps) the first fragments of the NEXT GEMM
+// of the forward, so that no GEMM opens with an exposed L2 round trip and no separate per-GEMM prefetch registers
+// exist (round 2: 2 + 2 + 3 fragments = 84 registers; now RD = 4 fragments = 48).  Every GEMM has a multiple of RD
+// steps, so the slot phase is 0 at every GEMM boundary.  PF = false: the consumer that follows has no registers for
+// the ring while its per-jet chain runs and primes it itself (ring_prime).
+template <int RD>
+struct WRing {
+  Frag16 s[RD];
+};
+// fragment g of the matrix at woff -> one ring slot (three planes, 3 KiB per wave)
+__device__ __forceinline__ void frag_load(Frag16& f, WRsrc R, int woff, int g, int lane16) {
+#ifdef MMB_WHATIF_ONEPLANE     // developer timing build (wrong results on purpose): one third of the weight-fragment bytes
+  f.p[0] = wload(R, woff, (g * 3) * 64, lane16);
+  f.p[1] = f.p[0];
+  f.p[2] = f.p[0];
+#else
+  ffor<3>([&](auto pc) { constexpr int pl = decltype(pc)::v; f.p[pl] = wload(R, woff, (g * 3 + pl) * 64, lane16); });
+#endif
+}
+template <int RD>
+__device__ __forceinline__ void ring_prime(WRing<RD>& ring, WRsrc R, int woff, int lane16) {
+  ffor<RD>([&](auto gc) { constexpr int g = decltype(gc)::v; frag_load(ring.s[g], R, woff, g, lane16); });
+}
+// registers 8jj..8jj+7 of a tile -> the three planes of one B operand
+template <int JJ>
+__device__ __forceinline__ void split_half(const f32x16& xt, bf16x8& h, bf16x8& m, bf16x8& l) {
+  const float v[8] = {xt[8 * JJ + 0], xt[8 * JJ + 1], xt[8 * JJ + 2], xt[8 * JJ + 3],
+                      xt[8 * JJ + 4], xt[8 * JJ + 5], xt[8 * JJ + 6], xt[8 * JJ + 7]};
+  split8(v, h, m, l);
+}
+template <int KT, int OT, int RD, bool PF, typename TileFn>
+__device__ __forceinline__ void mma_r(f32x16 (&acc)[OT], TileFn&& tile, WRsrc R, int woff, int next_woff, int lane16,
+                                      WRing<RD>& ring) {
+  constexpr int NG = KT * 2 * OT;
+  static_assert(NG % RD == 0 && NG >= RD, "every GEMM must be a whole number of ring turns");
+#ifdef MMB_WHATIF_NOGEMM          // developer timing build (wrong results on purpose): what the forward costs without its GEMMs
+  return;
+#endif
+  ffor<KT>([&](auto fc) {
+    constexpr int ft = decltype(fc)::v;
+    decltype(auto) xt = tile(IF<ft>{});
+    ffor<2>([&](auto jc) {
+      constexpr int jj = decltype(jc)::v;
+      bf16x8 bh, bm, bl;
+      split_half<jj>(xt, bh, bm, bl);
+      ffor<OT>([&](auto oc) {
+        constexpr int ot = decltype(oc)::v;
+        constexpr int g = (ft * 2 + jj) * OT + ot;
+        constexpr int cur = g % RD;
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, ring.s[cur].p[0]), am = __builtin_bit_cast(bf16x8, ring.s[cur].p[1]),
+                     al = __builtin_bit_cast(bf16x8, ring.s[cur].p[2]);
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[ot], 0, 0, 0);
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[ot], 0, 0, 0);
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[ot], 0, 0, 0);
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[ot], 0, 0, 0);
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[ot], 0, 0, 0);
+        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[ot], 0, 0, 0);
+        if constexpr (g + RD < NG) {
+          frag_load(ring.s[cur], R, woff, g + RD, lane16);
+        } else if constexpr (PF) {               // no run-time condition here: a branch in the stream makes the
+          frag_load(ring.s[cur], R, next_woff, g + RD - NG, lane16);       // wait-count pass drain the queue at the join
+        }
+        // nothing crosses: without it the scheduler sinks the refill to its first use under register pressure (load,
+        // vmcnt(0), MFMA -- the ring undone)
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  });
+}
+
+// ---- per-jet matvecs of the chain, round 3.  out[o] = act(sum_k W^T[k][o] v(k) + b[o]) (+ add[o]).
+// Lane = og * PARTS + part.  The PARTS partial sums of an output group sit in ADJACENT lanes, so the fold is DPP only
+// for PARTS <= 16 (quad_perm, quad_perm, row_half_mirror, row_mirror: no LDS-pipe exchange, no lgkmcnt wait).  A lane
+// owns ITER CONSECUTIVE rows k = part*ITER + it: its slice of the input vector is ITER/4 ds_read_b128 issued together
+// (round 2 and the first version of this: one ds_read_b32 + wait per row, 36 dependent LDS latencies in fc_glob1 of a
+// 128-wide encoder).  The input vector is stored with one slot group of ITERP >= ITER floats per partition
+// (vidx): ITERP = ITER rounded up to the read width, so that the reads stay 16-byte aligned for any K.  The weights
+// come through BUFFER loads -- lane part of the address in one VGPR, the row in the scalar offset -- in batches of BS
+// rows: prefetch() requests the first batch (and the bias) as early as the caller can afford the registers, i.e.
+// before the input vector exists; run() requests batch b + 1 before it multiplies batch b.  No barrier inside: the
+// caller publishes `out`.
+template <int K, int O>
+struct MV {
+  static_assert((O & (O - 1)) == 0 && O >= 8 && O <= 128, "MV: O must be a power of two in [8,128]");
+  static constexpr int OW = O / 4;                                   // outputs per wave
+  static constexpr int VW = OW >= 16 ? 4 : (OW >= 8 ? 2 : 1);        // outputs per lane
+  static constexpr int G = OW / VW;                                  // lane groups along the outputs
+  static constexpr int PARTS = 64 / G;                               // k-partitions: the low lane bits
+  static constexpr int ITER = (K + PARTS - 1) / PARTS;               // rows per lane
+  static constexpr bool RAGGED = (K % PARTS) != 0;                   // the last partitions own rows >= K: clamped, input 0
+  static constexpr int VR = ITER >= 4 ? 4 : (ITER >= 2 ? 2 : 1);     // floats per input read
+  static constexpr int ITERP = (ITER + VR - 1) / VR * VR;            // slot group of a partition in the input vector
+  static constexpr int KPAD = PARTS * ITERP;                         // floats of the stored input vector
+  static constexpr int BS = 16;                                      // rows per batch (<= 64 registers)
+  static constexpr int NB = (ITER + BS - 1) / BS;
+  typedef float vec __attribute__((ext_vector_type(VW)));
+  template <int B>
+  static constexpr int bsize() { return (ITER - B * BS) < BS ? (ITER - B * BS) : BS; }
+  struct Pre {
+    vec w[bsize<0>()];
+    vec bv;
+  };
+  // where element k of the input vector is stored
+  static __device__ __forceinline__ constexpr int vidx(int k) { return (k / ITER) * ITERP + (k % ITER); }
+
+  static __device__ __forceinline__ vec ld(WRsrc R, int voff, int soff_floats) {
+    if constexpr (VW == 4) {
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(R, voff, soff_floats * 4, 0);
+      return __builtin_bit_cast(vec, v);
+    } else if constexpr (VW == 2) {
+      const auto v = __builtin_amdgcn_raw_buffer_load_b64(R, voff, soff_floats * 4, 0);
+      return __builtin_bit_cast(vec, v);
+    } else {
+      const auto v = __builtin_amdgcn_raw_buffer_load_b32(R, voff, soff_floats * 4, 0);
+      return __builtin_bit_cast(vec, v);
+    }
+  }
+  // byte offset of this lane's first weight row; rows >= K (ragged K) are clamped to row K-1 -- their input is 0, but
+  // the buffer holds bf16 planes after the fp32 part, whose bits may read as NaN
+  template <int IT>
+  static __device__ __forceinline__ int voff(int part, int o0) {
+    int row = part * ITER;
+    if constexpr (RAGGED) row = (row + IT < K ? row + IT : K - 1) - IT;
+    return (row * O + o0) * 4;
+  }
+  template <int B>
+  static __device__ __forceinline__ void load_batch(vec* w, WRsrc R, int wt_off, int part, int o0) {
+    ffor<bsize<B>()>([&](auto ic) { constexpr int it = B * BS + decltype(ic)::v;
+      w[decltype(ic)::v] = ld(R, voff<it>(part, o0), wt_off + it * O); });
+  }
+  template <bool BIAS = true>
+  static __device__ __forceinline__ void prefetch(Pre& p, WRsrc R, int wt_off, int b_off, int tid_) {
+    const int tid = opaque(tid_);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int part = lane & (PARTS - 1), o0 = wave * OW + (lane / PARTS) * VW;
+    load_batch<0>(p.w, R, wt_off, part, o0);
+    if constexpr (BIAS) p.bv = ld(R, o0 * 4, b_off);
+    else ffor<VW>([&](auto ec) { p.bv[decltype(ec)::v] = 0.0f; });
+  }
+  // v: the input vector in LDS in the vidx layout (ITERP == ITER: the plain vector; rows past K are masked here)
+  template <int ACT>
+  static __device__ __forceinline__ void run(const Pre& p, WRsrc R, int wt_off, const float* v, float* out,
+                                             const float* add, int tid_, float* pre = nullptr) {
+    const int tid = opaque(tid_);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int part = lane & (PARTS - 1), o0 = wave * OW + (lane / PARTS) * VW;
+    vec acc;
+    ffor<VW>([&](auto ec) { acc[decltype(ec)::v] = 0.0f; });
+    vec wn[NB > 1 ? BS : 1];
+    ffor<NB>([&](auto bc) {
+      constexpr int b = decltype(bc)::v;
+      constexpr int nrow = bsize<b>(), nslot = (nrow + VR - 1) / VR * VR;       // BS is a multiple of 4: aligned reads
+      vec wc[nrow];
+      ffor<nrow>([&](auto ic) { constexpr int i = decltype(ic)::v;
+        if constexpr (b == 0) wc[i] = p.w[i]; else wc[i] = wn[i]; });
+      if constexpr (b + 1 < NB) load_batch<b + 1>(wn, R, wt_off, part, o0);
+      float vv[nslot];
+      ffor<nslot / VR>([&](auto jc) { constexpr int j = decltype(jc)::v;
+        const float* src = v + part * ITERP + b * BS + VR * j;
+        if constexpr (VR == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(src);
+          vv[4 * j] = t.x; vv[4 * j + 1] = t.y; vv[4 * j + 2] = t.z; vv[4 * j + 3] = t.w;
+        } else if constexpr (VR == 2) {
+          const float2 t = *reinterpret_cast<const float2*>(src);
+          vv[2 * j] = t.x; vv[2 * j + 1] = t.y;
+        } else {
+          vv[j] = *src;
+        } });
+      // ragged K: the last partitions own rows >= K; their weights are row K-1's (clamped) and whatever sits behind the
+      // input vector in LDS takes no part
+      ffor<nrow>([&](auto ic) { constexpr int i = decltype(ic)::v;
+        if constexpr (RAGGED) acc += wc[i] * (part * ITER + b * BS + i < K ? vv[i] : 0.0f);
+        else acc += wc[i] * vv[i]; });
+    });
+    ffor<ilog2(PARTS)>([&](auto bc) {
+      constexpr int bit = decltype(bc)::v;
+      ffor<VW>([&](auto ec) { constexpr int e = decltype(ec)::v;
+        if constexpr (bit == 0) acc[e] += dpp_mov<0xB1>(acc[e]);
+        else if constexpr (bit == 1) acc[e] += dpp_mov<0x4E>(acc[e]);
+        else if constexpr (bit == 2) acc[e] += dpp_mov<0x141>(acc[e]);      // row_half_mirror: quads are uniform by now
+        else if constexpr (bit == 3) acc[e] += dpp_mov<0x140>(acc[e]);      // row_mirror: half rows are uniform by now
+        else acc[e] += lane_xchg<bit>(acc[e]); });
+    });
+    if (part == 0) {
+      ffor<VW>([&](auto ec) {
+        constexpr int e = decltype(ec)::v;
+        const float z = acc[e] + p.bv[e];
+        if (pre) pre[o0 + e] = z;
+        float t = act_f<ACT>(z);
+        if (add) t += add[o0 + e];
+        out[o0 + e] = t;
+      });
+    }
+  }
+};
+
+// The input of fc_glob1 / mlp_global.0 in the layout of its consumer CMV (MV::vidx): element k = [sum/cnt, 0.01 sum]
+// of the four wave partials (epic.py:100-107: ONE division per feature, by the thread that owns it -- round 2
+// evaluated it per consumer lane, 4..16 IEEE divisions per lane and layer), then the `ntail` floats of `tail` (global
+// vector / context), zeros in every other slot.  Caller: barrier before and after.
+template <int H, class CMV>
+__device__ __forceinline__ void pooled_combine(float* pooled, const float* partial, float cnt, const float* tail,
+                                               int ntail, int tid_) {
+  const int tid = opaque(tid_);
+  ffor<(CMV::KPAD + FE_THREADS - 1) / FE_THREADS>([&](auto rc) {
+    const int s = tid + decltype(rc)::v * FE_THREADS;
+    const int part = s / CMV::ITERP, j = s % CMV::ITERP, k = part * CMV::ITER + j;
+    float v = 0.0f;
+    if (j < CMV::ITER && k < 2 * H) {
+      const int f = k >= H ? k - H : k;
+      const float sum = (partial[f] + partial[128 + f]) + (partial[256 + f] + partial[384 + f]);
+      v = k >= H ? sum * 0.01f : sum / cnt;
+    } else if (j < CMV::ITER && k < 2 * H + ntail) {
+      v = tail[k - 2 * H];
+    }
+    if (s < CMV::KPAD) pooled[s] = v;
   });
 }
 

@@ -45,54 +45,173 @@ __device__ unsigned long long fe_prof[16];
 #else
 #define FE_PROF(L, cat) do { } while (0)
 #endif
-enum { PF_EMBED = 0, PF_POOL, PF_GLOB1, PF_GLOB2, PF_DVEC, PF_LOC1, PF_LOC2, PF_EPI, PF_OUT, PF_PROJ_MMA, PF_HEAD, PF_STEP, PF_N };
+enum { PF_EMBED = 0, PF_POOL, PF_GLOB1, PF_GLOB2, PF_DVEC, PF_LOC1, PF_LOC2, PF_EPI, PF_OUT, PF_PROJ_MMA, PF_HEAD, PF_STEP, PF_X1, PF_X2, PF_X3, PF_N };
 
 // ------------------------------------------------------------------ one EPiC encoder ----
-// x: HT tiles (in/out), skip: HT tiles.  Global vector in L.gcur.  `li` walks the descriptors.
-template <int HT, int ET, int G>
+// What every stage of a forward needs besides its tiles
+struct FCtx {
+  const float* P;          // packed parameters
+  WRsrc R;                 // ... as a buffer resource
+  Lds& L;
+  float m;                 // this lane's particle mask
+  int tid, lane, wave, half, lane16;
+  const float* ctab;       // (n_c_layers,128) time vectors W_t temb of the CURRENT grid point (CT kernels)
+};
+
+// Issue priority of this wave against the other jet's wave on the same SIMD (arbitration is by priority, then age).
+// The per-jet chain is a string of short dependent steps between barriers: when the partner sits in a GEMM -- MFMAs
+// back to back with vector work in every gap -- an equal-priority chain wave only gets the leftover issue slots and
+// the jet's three other waves wait at the next barrier for it.  Chain: high priority; GEMM stream: low.
+#ifndef MMB_PRIO_CHAIN
+#define MMB_PRIO_CHAIN 2
+#endif
+__device__ __forceinline__ void prio_chain() { __builtin_amdgcn_s_setprio(MMB_PRIO_CHAIN); }
+__device__ __forceinline__ void prio_gemm() { __builtin_amdgcn_s_setprio(0); }
+
+// __syncthreads() that the machine scheduler does not move loads across either: the weight prefetches of the chain are
+// buffer loads the scheduler considers free to hoist over s_barrier -- into the pooling butterfly, where their
+// registers do not exist yet (they went to scratch as they arrived: load, vmcnt(0), scratch store).
+__device__ __forceinline__ void sync_pin() {
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// One float4 per lane of wave `w` moves a per-layer vector (time vector from the table, biases) from global memory into
+// LDS: requested at the stage's entry, written in the interval before the barrier that publishes it, so that the
+// accumulator initialisation reads LDS instead of waiting on L2 in front of a GEMM (round 2: flat loads + vmcnt(0)).
+struct Stage {
+  float4 v;
+};
+// No branch and no select on the loaded value: lanes past the vector re-read its last float4 (a select against zero made
+// the compiler wait for the load -- vmcnt(0), i.e. for every weight prefetch issued just before it -- at once).
+__device__ __forceinline__ void stage_issue(Stage& s, const float* src, int n, int lane) {
+  const int o = 4 * lane < n ? 4 * lane : n - 4;
+  s.v = *reinterpret_cast<const float4*>(src + o);
+}
+// up to three vectors, one per wave (pointer chosen by wave index, ONE load instruction: two conditional loads into the
+// same registers made the second one wait for the first -- vmcnt(0) again)
+__device__ __forceinline__ void stage_issue3(Stage& s, const float* a, const float* b, const float* c3, int n, int wave,
+                                             int lane) {
+  const float* src = wave == 0 ? a : (wave == 1 ? b : c3);
+  stage_issue(s, src, n, lane);
+}
+__device__ __forceinline__ void stage_commit(const Stage& s, float* dst, int n, int lane) {
+  if (4 * lane < n) *reinterpret_cast<float4*>(dst + 4 * lane) = s.v;
+}
+
+// offsets of the LDS copy of the descriptors: wave-uniform, used as scalar offsets of buffer loads
+__device__ __forceinline__ int desc_wx(const Lds& L, int i) { return __builtin_amdgcn_readfirstlane(L.desc[i].wx); }
+// one field of descriptor i, fetched where it is used (four whole descriptors per layer held in SGPRs were spilling
+// into VGPR lanes, and offsets that lost their SGPR turned buffer loads into waterfall loops)
+enum { F_WX = 0, F_WT = 1, F_WG = 2, F_B = 3 };
+template <int F>
+__device__ __forceinline__ int dfield(const Lds& L, int i) {
+  return __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(L.desc)[4 * i + F]);
+}
+// N consecutive descriptors in ONE LDS round trip (N ds_read_b128 issued together), kept in VGPRs; fld<F>(d[i]) moves a
+// field to an SGPR where it is used.  (One ds_read_b32 + wait per field was nine dependent LDS latencies per layer.)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <int N>
+struct DescV {
+  i32x4 d[N];
+};
+template <int N>
+__device__ __forceinline__ DescV<N> load_descs(const Lds& L, int i) {
+  DescV<N> r;
+  ffor<N>([&](auto nc) { constexpr int n = decltype(nc)::v; r.d[n] = reinterpret_cast<const i32x4*>(L.desc)[i + n]; });
+  return r;
+}
+template <int F>
+__device__ __forceinline__ int fld(const i32x4& d) { return __builtin_amdgcn_readfirstlane(d[F]); }
+
+// x: HT tiles (in/out), skip: HT tiles.  Global vector in L.gcur.  `li` walks the descriptors (LDS copy).
+// RD: depth of the weight-fragment ring (fused_common.h: mma_r).  CT: the time vectors come from the per-grid-point
+// table (generation); otherwise they are matvecs on the time embedding (single forward, training).
+template <int HT, int ET, int G, int RD, bool CT>
 struct Epic {
   static constexpr int H = 32 * HT;
+  // The ring is carried through the per-jet chain only where the chain leaves the registers for it (fc_glob1 of a
+  // 128-wide encoder holds 144 weights per lane): otherwise the layer primes it after fc_glob1.
+  static constexpr bool CARRY = HT <= 2;
+  typedef MV<2 * H + G, H> MVA;      // fc_glob1
+  typedef MV<H, G> MVB;              // fc_glob2
+  typedef MV<G, H> MVC;              // global-vector block of fc_loc1 (+ its bias)
+  typedef MV<ET, H> MVT;             // time block of a 32*HT-wide layer
 
-  // pooled = [mean, 0.01*sum] of the wave partials (without the tail) -> the tape's (B, 2H) tensor
-  template <class TR>
+  template <class CMV, class TR>
   static __device__ __forceinline__ void save_pooled(TR& tr, Lds& L, int tid) {
     if constexpr (TR::on) {
       float* dst = tr.row(2 * H);
-      const PooledIn<H> pin{L.partial, nullptr, L.cnt};
       if (dst != nullptr)
-        for (int k = tid; k < 2 * H; k += FE_THREADS) dst[k] = pin(k);
+        for (int k = tid; k < 2 * H; k += FE_THREADS) dst[k] = L.pooled[CMV::vidx(k)];
     }
   }
 
   // EPiCLayer (epic.py:187-208) + the encoder-level skip add (:89-90).  skipf(IF<t>) yields skip tile t.
+  // next_wx: first fragment of the GEMM that follows this layer (< 0: that consumer primes the ring itself).
   // Training slots: pooled, gh, g_new, g_out, sign bits of lh's pre-activation, lh, sign bits of y1 (the
-  // leaky-relu input behind l_out), l_out: the reverse pass takes the two derivatives from 2 x 8 bytes per lane instead of
-  // re-reading lh, l_out and the skip tensor.
+  // leaky-relu input behind l_out), l_out.
+  // Five intervals separated by barriers; every global load of the chain is requested in the first one:
+  //   I0 pool partials | I1 pooled vector | I2 fc_glob1 (+ time vector, staged vectors) | I3 fc_glob2 | I4 d-vector, g
   template <typename SkipFn, class TR>
-  static __device__ __forceinline__ void layer(f32x16 (&x)[HT], SkipFn&& skipf, bool use_skip,
-                                               const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
-                                               float m, int tid, const float* ctab, int& ci, TR& tr) {
-    const int lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-    const WRsrc R = weight_rsrc(P);
-    const LDesc g1 = D[li], g2 = D[li + 1], l1 = D[li + 2], l2 = D[li + 3];
+  static __device__ __forceinline__ void layer(f32x16 (&x)[HT], SkipFn&& skipf, bool use_skip, FCtx& c, int& li, int& ci,
+                                               int next_wx, WRing<RD>& ring, TR& tr) {
+    Lds& L = c.L;
+    const int tid = c.tid, lane = c.lane, wave = c.wave, half = c.half;
+    prio_chain();
+    const DescV<4> dv = load_descs<4>(L, li);     // fc_glob1, fc_glob2, fc_loc1, fc_loc2
     li += 4;
     FE_PROF(L, PF_EPI);
-    pool_partials<HT>(x, m, L.partial, wave, lane);
-    AFrag<HT> pre1, pre2;
-    if constexpr (HT <= 2) mma_prefetch(pre1, R, l1.wx, lane);   // arrives under the per-jet chain
-    __syncthreads();
+#ifndef MMB_WHATIF_NOCHAIN        // developer timing build (wrong results on purpose): what the forward costs without the per-jet chain
+    typename MVA::Pre wa;
+    typename MVT::Pre wt;
+    Stage st;
+    if constexpr (CARRY) MVA::prefetch(wa, c.R, fld<F_WT>(dv.d[0]), fld<F_B>(dv.d[0]), tid);      // a narrow encoder has the registers now
+    {
+      const float* b2 = c.P + fld<F_B>(dv.d[3]);
+      stage_issue3(st, CT ? c.ctab + (int64_t)ci * 128 : b2, b2, b2, H, wave, lane);
+    }
+    if constexpr (!CT) MVT::template prefetch<false>(wt, c.R, fld<F_WT>(dv.d[2]), 0, tid);
+    ++ci;
+    FE_PROF(L, PF_X1);
+    pool_partials<HT>(x, c.m, L.partial, wave, lane);
+    FE_PROF(L, PF_X2);
+    typename MVB::Pre wb;
+    typename MVC::Pre wc;
+    if constexpr (CARRY) {
+      MVB::prefetch(wb, c.R, fld<F_WT>(dv.d[1]), fld<F_B>(dv.d[1]), tid);
+      MVC::prefetch(wc, c.R, fld<F_WG>(dv.d[2]), fld<F_B>(dv.d[2]), tid);
+    }
+    sync_pin();                                                             // 1: wave partials
+    // a wide encoder only now: requested next to the pooling butterfly, the 64 registers of the first batch went to
+    // scratch as they arrived (load, vmcnt(0), scratch store: worse than no prefetch)
+    if constexpr (!CARRY) MVA::prefetch(wa, c.R, fld<F_WT>(dv.d[0]), fld<F_B>(dv.d[0]), tid);
     FE_PROF(L, PF_POOL);
-    save_pooled(tr, L, tid);
-    WaveMV<2 * H + G, H>::template run<MMB_ACT_LRELU>(P + g1.wt, P + g1.b, PooledIn<H>{L.partial, L.gcur, L.cnt}, L.gh,
-                                                      nullptr, tid);
+    pooled_combine<H, MVA>(L.pooled, L.partial, L.cnt, L.gcur, G, tid);
+    sync_pin();                                                             // 2: pooled vector
+    FE_PROF(L, PF_X3);
+    save_pooled<MVA>(tr, L, tid);
+    MVA::template run<MMB_ACT_LRELU>(wa, c.R, fld<F_WT>(dv.d[0]), L.pooled, L.gh, nullptr, tid);
+    if constexpr (CT) {
+      if (wave == 0) stage_commit(st, L.cvec, H, lane);
+    } else {
+      MVT::template run<MMB_ACT_NONE>(wt, c.R, fld<F_WT>(dv.d[2]), L.temb, L.cvec, nullptr, tid);
+    }
+    if (wave == 1) stage_commit(st, L.bvec, H, lane);
+    if constexpr (!CARRY) {                // fc_glob1's 144 weights per lane are gone: now the rest fits
+      MVB::prefetch(wb, c.R, fld<F_WT>(dv.d[1]), fld<F_B>(dv.d[1]), tid);
+      MVC::prefetch(wc, c.R, fld<F_WG>(dv.d[2]), fld<F_B>(dv.d[2]), tid);
+      ring_prime(ring, c.R, fld<F_WX>(dv.d[2]), c.lane16);
+    }
+    sync_pin();                                                             // 3: gh, time vector, second bias
     if constexpr (TR::on) tr.vec(L.gh, H, tid);
     FE_PROF(L, PF_GLOB1);
-    matvec<MMB_ACT_NONE, H, G>(P + g2.wt, P + g2.b, L.gh, L.gnew, L.gcur, tid);      // g' = g + fc_glob2(.)
+    MVB::template run<MMB_ACT_NONE>(wb, c.R, fld<F_WT>(dv.d[1]), L.gh, L.gnew, L.gcur, tid);   // g' = g + fc_glob2(.)
+    sync_pin();                                                             // 4: g'
     if constexpr (TR::on) tr.vec(L.gnew, G, tid);
     FE_PROF(L, PF_GLOB2);
-    const float* cv = time_vec<ET, H>(ctab, ci, P + l1.wt, L, tid);
-    matvec<MMB_ACT_NONE, G, H>(P + l1.wg, P + l1.b, L.gnew, L.dvec, nullptr, tid);
-    FE_PROF(L, PF_DVEC);
+    MVC::template run<MMB_ACT_NONE>(wc, c.R, fld<F_WG>(dv.d[2]), L.gnew, L.dvec, nullptr, tid);
     if constexpr (TR::on) {
       const bool dr = tr.drop_p > 0.0f;
       if (dr) ++tr.off;
@@ -113,22 +232,26 @@ struct Epic {
     } else {
       if (tid < G) L.gcur[tid] = lrelu_f(L.gnew[tid]) + (use_skip ? L.gskip[tid] : 0.0f);
     }
+    sync_pin();                                                             // 5: d-vector, g
+#else
+    ++ci;
+    if constexpr (!CARRY) ring_prime(ring, c.R, fld<F_WX>(dv.d[2]), c.lane16);
+#endif
+    FE_PROF(L, PF_DVEC);
+    prio_gemm();
     f32x16 lh[HT];
-    if constexpr (HT > 2) mma_prefetch(pre1, R, l1.wx, lane);    // (wide encoder: no registers to spare earlier)
-    acc_init<HT>(lh, m, cv, L.dvec, half);
-    if constexpr (HT <= 2) mma_prefetch(pre2, R, l2.wx, lane);   // arrives under the first GEMM
-    mma_x<HT, HT>(lh, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, R, l1.wx, lane, pre1);
+    acc_init<HT>(lh, c.m, L.cvec, L.dvec, half);
+    mma_r<HT, HT, RD, true>(lh, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, c.R, fld<F_WX>(dv.d[2]), fld<F_WX>(dv.d[3]), c.lane16, ring);
     if constexpr (TR::on) tr.bits(sign_bits<HT>(lh), tid);
     act_tiles<HT, MMB_ACT_LRELU>(lh);
-    if constexpr (HT > 2) mma_prefetch(pre2, R, l2.wx, lane);    // before the stores: vmcnt is one in-order counter
     if constexpr (TR::on) tr.template tiles<HT>(lh, half);
     FE_PROF(L, PF_LOC1);
     // x <- (x + b2) + W2 lh : the residual rides in the accumulator, x's registers ARE the accumulator
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
       ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
-        const float4 bv = *reinterpret_cast<const float4*>(P + l2.b + 32 * t + 8 * q + 4 * half);
+        const float4 bv = *reinterpret_cast<const float4*>(L.bvec + 32 * t + 8 * q + 4 * half);
         x[t][4 * q + 0] += bv.x; x[t][4 * q + 1] += bv.y; x[t][4 * q + 2] += bv.z; x[t][4 * q + 3] += bv.w; }); });
-    mma_x<HT, HT>(x, [&](auto fc) -> const f32x16& { return lh[decltype(fc)::v]; }, R, l2.wx, lane, pre2);
+    mma_r<HT, HT, RD, CARRY>(x, [&](auto fc) -> const f32x16& { return lh[decltype(fc)::v]; }, c.R, fld<F_WX>(dv.d[3]), next_wx, c.lane16, ring);
     FE_PROF(L, PF_LOC2);
     bool dr = false;
     if constexpr (TR::on) {
@@ -154,26 +277,41 @@ struct Epic {
         ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; x[t][r] += sk[r]; });
       } });
     if constexpr (TR::on) tr.template tiles<HT>(x, half);
-    __syncthreads();                                   // gcur settled before the next pooled build
     FE_PROF(L, PF_EPI);
   }
 
   // output layer: wn Linear on cat[t, x, g] (epic.py:93-96); OTO output tiles, OW = true output width
   // Training slot: out (only when OW is a whole number of tiles).
-  template <int OTO, int OW, class TR>
-  static __device__ __forceinline__ void output(f32x16 (&out)[OTO], const f32x16 (&x)[HT],
-                                                const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
-                                                float m, int tid, const float* ctab, int& ci, TR& tr) {
-    const int lane = tid & 63, half = lane >> 5;
-    const WRsrc R = weight_rsrc(P);
-    const LDesc o = D[li];
+  // PFN: the GEMM after this one takes its first fragments from this one's tail (false: it primes the ring itself)
+  template <int OTO, int OW, bool PFN, class TR>
+  static __device__ __forceinline__ void output(f32x16 (&out)[OTO], const f32x16 (&x)[HT], FCtx& c, int& li, int& ci,
+                                                int next_wx, WRing<RD>& ring, TR& tr) {
+    Lds& L = c.L;
+    const int tid = c.tid, lane = c.lane, wave = c.wave, half = c.half;
+    typedef MV<G, OW> MVO;               // the packed per-jet blocks have the TRUE output width (8 logits: UniModalEPiC)
+    typedef MV<ET, OW> MVTO;
+    prio_chain();
+    const DescV<1> dv = load_descs<1>(L, li);
     li += 1;
-    AFrag<OTO> pre;
-    mma_prefetch(pre, R, o.wx, lane);
-    const float* cv = time_vec<ET, OW>(ctab, ci, P + o.wt, L, tid);
-    matvec<MMB_ACT_NONE, G, OW>(P + o.wg, P + o.b, L.gcur, L.dvec, nullptr, tid);
-    acc_init<OTO>(out, m, cv, L.dvec, half);
-    mma_x<HT, OTO>(out, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, R, o.wx, lane, pre);
+    typename MVO::Pre wo;
+    MVO::prefetch(wo, c.R, fld<F_WG>(dv.d[0]), fld<F_B>(dv.d[0]), tid);
+    typename MVTO::Pre wt;
+    Stage st;
+    if constexpr (CT) stage_issue(st, c.ctab + (int64_t)ci * 128, 32 * OTO, lane);
+    else MVTO::template prefetch<false>(wt, c.R, fld<F_WT>(dv.d[0]), 0, tid);
+    ++ci;
+    if constexpr (!CARRY) ring_prime(ring, c.R, fld<F_WX>(dv.d[0]), c.lane16);
+    sync_pin();                        // every wave is past the accumulator initialisation of the stage before
+    MVO::template run<MMB_ACT_NONE>(wo, c.R, fld<F_WG>(dv.d[0]), L.gcur, L.dvec, nullptr, tid);
+    if constexpr (CT) {
+      if (wave == 0) stage_commit(st, L.cvec, 32 * OTO, lane);
+    } else {
+      MVTO::template run<MMB_ACT_NONE>(wt, c.R, fld<F_WT>(dv.d[0]), L.temb, L.cvec, nullptr, tid);
+    }
+    sync_pin();
+    prio_gemm();
+    acc_init<OTO>(out, c.m, L.cvec, L.dvec, half);
+    mma_r<HT, OTO, RD, PFN>(out, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, c.R, fld<F_WX>(dv.d[0]), next_wx, c.lane16, ring);
     if constexpr (TR::on && OW == 32 * OTO) tr.template tiles<OTO>(out, half);
     FE_PROF(L, PF_OUT);
   }
@@ -181,39 +319,64 @@ struct Epic {
   // EPiCProjection (epic.py:145-159) from KIN padded input tiles delivered by xin(IF<t>)
   // Training slots: p0 pre, p0 out, p2 pre, p2 out, pooled, q0 pre, q0 out, q2 pre, q2 out.
   template <int KIN, typename InFn, class TR>
-  static __device__ __forceinline__ void project(f32x16 (&x)[HT], InFn&& xin,
-                                                 const float* __restrict__ P, const LDesc* __restrict__ D, int& li, Lds& L,
-                                                 float m, int tid, const float* ctab, int& ci, TR& tr) {
-    const int lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-    const WRsrc R = weight_rsrc(P);
-    const LDesc p0 = D[li], p2 = D[li + 1], q0 = D[li + 2], q2 = D[li + 3];
+  static __device__ __forceinline__ void project(f32x16 (&x)[HT], InFn&& xin, FCtx& c, int& li, int& ci, int next_wx,
+                                                 WRing<RD>& ring, TR& tr) {
+    Lds& L = c.L;
+    const int tid = c.tid, lane = c.lane, wave = c.wave, half = c.half;
+    typedef MV<2 * H + ET, H> MVQ0;
+    prio_chain();
+    const DescV<4> dv = load_descs<4>(L, li);     // mlp_local.0, mlp_local.2, mlp_global.0, mlp_global.2
     li += 4;
-    AFrag<HT> pre0, pre2;
-    mma_prefetch(pre0, R, p0.wx, lane);
-    mma_prefetch(pre2, R, p2.wx, lane);
-    const float* cv = time_vec<ET, H>(ctab, ci, P + p0.wt, L, tid);
+    typename MVT::Pre wt;
+    Stage st;
+    {
+      const float* b0 = c.P + fld<F_B>(dv.d[0]);
+      stage_issue3(st, CT ? c.ctab + (int64_t)ci * 128 : b0, b0, c.P + fld<F_B>(dv.d[1]), H, wave, lane);
+    }
+    if constexpr (!CT) MVT::template prefetch<false>(wt, c.R, fld<F_WT>(dv.d[0]), 0, tid);
+    ++ci;
+    sync_pin();                        // every wave is past the accumulator initialisation of the stage before
+    if constexpr (CT) {
+      if (wave == 0) stage_commit(st, L.cvec, H, lane);
+    } else {
+      MVT::template run<MMB_ACT_NONE>(wt, c.R, fld<F_WT>(dv.d[0]), L.temb, L.cvec, nullptr, tid);
+    }
+    if (wave == 1) stage_commit(st, L.dvec, H, lane);
+    if (wave == 2) stage_commit(st, L.bvec, H, lane);
+    sync_pin();
+    prio_gemm();
     f32x16 h[HT];
-    acc_init<HT>(h, m, cv, P + p0.b, half);
-    mma_x<KIN, HT>(h, xin, R, p0.wx, lane, pre0);
+    acc_init<HT>(h, c.m, L.cvec, L.dvec, half);
+    mma_r<KIN, HT, RD, true>(h, xin, c.R, fld<F_WX>(dv.d[0]), fld<F_WX>(dv.d[1]), c.lane16, ring);
     if constexpr (TR::on) tr.template tiles<HT>(h, half);
     act_tiles<HT, MMB_ACT_GELU>(h);
     if constexpr (TR::on) tr.template tiles<HT>(h, half);
-    acc_init<HT>(x, 0.0f, nullptr, P + p2.b, half);
-    mma_x<HT, HT>(x, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, R, p2.wx, lane, pre2);
+    acc_init<HT>(x, 0.0f, nullptr, L.bvec, half);
+    mma_r<HT, HT, RD, CARRY>(x, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, c.R, fld<F_WX>(dv.d[1]), next_wx, c.lane16, ring);
     if constexpr (TR::on) tr.template tiles<HT>(x, half);
     act_tiles<HT, MMB_ACT_GELU>(x);
     if constexpr (TR::on) tr.template tiles<HT>(x, half);
     FE_PROF(L, PF_PROJ_MMA);
-    pool_partials<HT>(x, m, L.partial, wave, lane);
-    __syncthreads();                                   // context = time embedding (dim_context = Et)
-    save_pooled(tr, L, tid);
+    prio_chain();
+    typename MVQ0::Pre wq0;
+    if constexpr (CARRY) MVQ0::prefetch(wq0, c.R, fld<F_WT>(dv.d[2]), fld<F_B>(dv.d[2]), tid);
+    pool_partials<HT>(x, c.m, L.partial, wave, lane);
+    typename MV<H, G>::Pre wq2;
+    if constexpr (CARRY) MV<H, G>::prefetch(wq2, c.R, fld<F_WT>(dv.d[3]), fld<F_B>(dv.d[3]), tid);
+    sync_pin();
+    if constexpr (!CARRY) MVQ0::prefetch(wq0, c.R, fld<F_WT>(dv.d[2]), fld<F_B>(dv.d[2]), tid);
+    pooled_combine<H, MVQ0>(L.pooled, L.partial, L.cnt, L.temb, ET, tid);          // context = time embedding
+    sync_pin();
+    save_pooled<MVQ0>(tr, L, tid);
     float* pre_q0 = nullptr;
     if constexpr (TR::on) pre_q0 = tr.row(H);
-    WaveMV<2 * H + ET, H>::template run<MMB_ACT_GELU>(P + q0.wt, P + q0.b, PooledIn<H>{L.partial, L.temb, L.cnt}, L.gh,
-                                                      nullptr, tid, pre_q0);
+    MVQ0::template run<MMB_ACT_GELU>(wq0, c.R, fld<F_WT>(dv.d[2]), L.pooled, L.gh, nullptr, tid, pre_q0);
+    if constexpr (!CARRY) MV<H, G>::prefetch(wq2, c.R, fld<F_WT>(dv.d[3]), fld<F_B>(dv.d[3]), tid);
+    sync_pin();
     float* pre_q2 = nullptr;
     if constexpr (TR::on) { tr.vec(L.gh, H, tid); pre_q2 = tr.row(G); }
-    matvec<MMB_ACT_GELU, H, G>(P + q2.wt, P + q2.b, L.gh, L.gcur, nullptr, tid, pre_q2);
+    MV<H, G>::template run<MMB_ACT_GELU>(wq2, c.R, fld<F_WT>(dv.d[3]), L.gh, L.gcur, nullptr, tid, pre_q2);
+    sync_pin();
     if constexpr (TR::on) tr.vec(L.gcur, G, tid);
     FE_PROF(L, PF_GLOB1);
   }
@@ -247,121 +410,165 @@ struct FusedArgs {
   const float* maskf;      // (B,N)
   const int32_t* counts;   // (B)
   int nb_branch1;          // EPiC layers of the discrete branch (nb_branch: the continuous one); they may differ
+  int n_desc;              // descriptors behind D (cached in LDS by every workgroup)
 };
 
-// embedded inputs of one particle as padded 32-feature tiles (embedder.py:74-80 + apply_mask)
+// ring depth of a width set: 4 fragments in flight where every GEMM of the model has a multiple of 4 steps (tiles of
+// 64+ features), else 2
 template <class DM>
-__device__ __forceinline__ void embed_tiles(f32x16& tc, f32x16& td, const float (&xp)[4], int kp, float m, const Lds& L,
-                                            int half) {
+constexpr int ring_depth_multi() { return DM::HBT >= 2 ? 4 : 2; }
+template <class DM>
+constexpr int ring_depth_uni() { return (DM::HT >= 2 && (DM::EDT * DM::HT) % 2 == 0) ? 4 : 2; }
+
+// embedded inputs of one particle as padded 32-feature tiles (embedder.py:74-80 + apply_mask): the continuous
+// features (br = 0) or the truncated token embedding (br = 1, quirk Q1); each is built right before the branch that
+// consumes it, so that neither occupies 16 registers while the other branch runs
+template <class DM, int BR>
+__device__ __forceinline__ void embed_tile(f32x16& t, const float (&xp)[4], int kp, float m, const Lds& L, int half) {
   ffor<16>([&](auto rc) {
     constexpr int r = decltype(rc)::v;
     const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
-    float c = 0.0f, d = 0.0f;
-    if (f < DM::EC) {
-      float s = 0.0f;
+    float v = 0.0f;
+    if constexpr (BR == 0) {
+      if (f < DM::EC) {
+        float s = 0.0f;
 #pragma unroll
-      for (int dd = 0; dd < DM::DC; ++dd) s += xp[dd] * L.cw[f * 4 + dd];
-      c = (s + L.cb[f]) * m;
+        for (int dd = 0; dd < DM::DC; ++dd) s += xp[dd] * L.cw[f * 4 + dd];
+        v = (s + L.cb[f]) * m;
+      }
+    } else {
+      if (f < DM::ED) v = truncf(L.table[kp * 32 + f] * m);           // quirk Q1
     }
-    if (f < DM::ED) d = truncf(L.table[kp * 32 + f] * m);           // quirk Q1
-    tc[r] = c;
-    td[r] = d;
+    t[r] = v;
   });
+}
+
+// One GELU head (multimodal_epic.py:188-189): Linear(cat[t, f_i, h_i]) -> GELU -> Linear.  in(IF<t>) yields the
+// 2*HBT input tiles; `o` receives the output tile; i0: descriptor of the first Linear.  Training slots:
+// pre-activation, hidden.
+template <class DM, int RD, bool CT, typename InFn, class TR>
+__device__ __forceinline__ void head(f32x16& o, InFn&& in, FCtx& c, int i0, int cslot,
+                                     int next_wx, WRing<RD>& ring, TR& tr) {
+  constexpr int HBT = DM::HBT, HFT = DM::HFT;
+  Lds& L = c.L;
+  const int tid = c.tid, lane = c.lane, wave = c.wave, half = c.half;
+  prio_chain();
+  const DescV<2> dv = load_descs<2>(L, i0);
+  typedef MV<DM::ET, DM::HB> MVT;
+  typename MVT::Pre wt;
+  Stage st;
+  {
+    // (the 32 floats of the second bias are followed by more parameters: reading HB of them is harmless)
+    const float* b0 = c.P + fld<F_B>(dv.d[0]);
+    stage_issue3(st, CT ? c.ctab + (int64_t)cslot * 128 : b0, b0, c.P + fld<F_B>(dv.d[1]), DM::HB, wave, lane);
+  }
+  if constexpr (!CT) MVT::template prefetch<false>(wt, c.R, fld<F_WT>(dv.d[0]), 0, tid);
+  sync_pin();                          // every wave is past the accumulator initialisation of the stage before
+  if constexpr (CT) {
+    if (wave == 0) stage_commit(st, L.cvec, DM::HB, lane);
+  } else {
+    MVT::template run<MMB_ACT_NONE>(wt, c.R, fld<F_WT>(dv.d[0]), L.temb, L.cvec, nullptr, tid);
+  }
+  if (wave == 1) stage_commit(st, L.dvec, DM::HB, lane);
+  if (wave == 2) stage_commit(st, L.bvec, 32, lane);
+  sync_pin();
+  prio_gemm();
+  f32x16 h[HBT];
+  acc_init<HBT>(h, c.m, L.cvec, L.dvec, half);
+  mma_r<HFT, HBT, RD, true>(h, in, c.R, fld<F_WX>(dv.d[0]), fld<F_WX>(dv.d[1]), c.lane16, ring);
+  if constexpr (TR::on) tr.template tiles<HBT>(h, half);
+  act_tiles<HBT, MMB_ACT_GELU>(h);
+  if constexpr (TR::on) tr.template tiles<HBT>(h, half);
+  f32x16 oo[1];
+  acc_init<1>(oo, 0.0f, nullptr, L.bvec, half);
+  mma_r<HBT, 1, RD, true>(oo, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, c.R, fld<F_WX>(dv.d[1]), next_wx, c.lane16, ring);
+  o = oo[0];
 }
 
 // Whole MultiModalEPiC forward for this jet.  which: 0 continuous head, 1 discrete head, 2 both.
 // hc: tile whose features 0..DC-1 are the drift; hd: tile whose features 0..V-1 are the logits.
+// The ring enters primed with the first fragments of the first GEMM (descriptor 0) and leaves primed the same way:
+// the last GEMM of a forward prefetches the first one of the next.
 // Training (TR = Train): slots in execution order -- per branch [projection 9, layers 8 each, output 1],
 // the concatenated global vector 1, fused encoder [layers 8 each, output 1], heads [pre, hidden] x 2.
-template <class DM, class TR>
+template <class DM, bool CT, class TR>
 __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* S, const float (&xp)[4], int kp, float m,
-                                            int which, f32x16& hc, f32x16& hd, int tid, TR& tr) {
-  constexpr int HBT = DM::HBT, HFT = DM::HFT;
+                                            int which, f32x16& hc, f32x16& hd, int tid,
+                                            WRing<ring_depth_multi<DM>()>& ring, TR& tr) {
+  constexpr int HBT = DM::HBT, HFT = DM::HFT, RD = ring_depth_multi<DM>();
+  typedef Epic<HBT, DM::ET, DM::GB, RD, CT> EB;
+  typedef Epic<HFT, DM::ET, DM::GF, RD, CT> EF;
   const int lane = tid & 63, half = lane >> 5;
+  FCtx c{A.P, weight_rsrc(A.P), L, m, tid, lane, tid >> 6, half, lane * 16, A.ctab};
   int li = 0, ci = 0;
-  f32x16 tc, td;
   FE_PROF(L, PF_STEP);
-  embed_tiles<DM>(tc, td, xp, kp, m, L, half);
-  FE_PROF(L, PF_EMBED);
   // S (LDS, HFT tiles) = cat[h1, h2]: fused-encoder input, its skip connection AND the heads' input
   // ---- two branch encoders (multimodal_epic.py:173-175)
   ffor<2>([&](auto bc) {
     constexpr int br = decltype(bc)::v;
-    f32x16 x[HBT], sk[HBT], out[HBT];
-    Epic<HBT, DM::ET, DM::GB>::template project<1>(x, [&](auto) -> const f32x16& { return br == 0 ? tc : td; }, A.P,
-                                                   A.D, li, L, m, tid, A.ctab, ci, tr);
-    if (tid < DM::GB) L.gskip[tid] = L.gcur[tid];
-    ffor<HBT>([&](auto t) { sk[decltype(t)::v] = x[decltype(t)::v]; });
-    __syncthreads();
+    f32x16 x[HBT], out[HBT], tin;
+    embed_tile<DM, br>(tin, xp, kp, m, L, half);
+    FE_PROF(L, PF_EMBED);
     const int nbb = br == 0 ? A.nb_branch : A.nb_branch1;
-    for (int i = 0; i < nbb; ++i)
-      Epic<HBT, DM::ET, DM::GB>::layer(x, [&](auto t) -> const f32x16& { return sk[decltype(t)::v]; },
-                                       A.use_skip != 0, A.P, A.D, li, L, m, tid, A.ctab, ci, tr);
-    Epic<HBT, DM::ET, DM::GB>::template output<HBT, DM::HB>(out, x, A.P, A.D, li, L, m, tid, A.ctab, ci, tr);
+    // descriptors: projection 4, layers 4 each, output 1
+    const int wx_after_proj = desc_wx(L, nbb > 0 ? li + 4 + 2 : li + 4);
+    EB::template project<1>(x, [&](auto) -> const f32x16& { return tin; }, c, li, ci, wx_after_proj, ring, tr);
+    if (tid < DM::GB) L.gskip[tid] = L.gcur[tid];        // read in the fourth interval of a layer: barriers in between
+    // the skip tiles wait in the upper half of S (free until this branch's own output goes there, or -- branch 0 --
+    // until branch 1's does): 16*HBT registers less across the layers
+    ffor<HBT>([&](auto t) { park_tile(S, HBT + decltype(t)::v, x[decltype(t)::v], tid); });
+    for (int i = 0; i < nbb; ++i) {
+      const int nx = desc_wx(L, i + 1 < nbb ? li + 4 + 2 : li + 4);
+      EB::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, HBT + decltype(t)::v, tid); }, A.use_skip != 0, c, li, ci, nx,
+                ring, tr);
+    }
+    // after this branch's output layer: the other branch's projection, or the fused encoder
+    int nx;
+    if constexpr (br == 0) nx = desc_wx(L, li + 1);
+    else nx = desc_wx(L, A.nb_fused_exec > 0 ? li + 1 + 2 : li + 1);
+    EB::template output<HBT, DM::HB, (br == 0 || EF::CARRY)>(out, x, c, li, ci, nx, ring, tr);
     ffor<HBT>([&](auto t) { park_tile(S, br * HBT + decltype(t)::v, out[decltype(t)::v], tid); });
     if (tid < DM::GB) L.gcat[br * DM::GB + tid] = L.gcur[tid];
-    __syncthreads();
   });
-  // ---- fused encoder, no projection (K2: nb_fused_exec = constructed - 1)
+  // ---- fused encoder, no projection (K2: nb_fused_exec = constructed - 1).  gcat / gcur / gskip are written and read
+  // by wave 0 here (LDS operations of one wave are in order); every other reader sits behind a barrier of the next stage
   if (tid < DM::GF) { L.gcur[tid] = L.gcat[tid]; L.gskip[tid] = L.gcat[tid]; }
   if constexpr (TR::on) tr.vec(L.gcat, DM::GF, tid);
-  __syncthreads();
   f32x16 x[HFT], f[HFT];
   ffor<HFT>([&](auto t) { x[decltype(t)::v] = fetch_tile(S, decltype(t)::v, tid); });
-  for (int i = 0; i < A.nb_fused_exec; ++i)
-    Epic<HFT, DM::ET, DM::GF>::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, decltype(t)::v, tid); },
-                                     A.use_skip != 0, A.P, A.D, li, L, m, tid, A.ctab, ci, tr);
-  Epic<HFT, DM::ET, DM::GF>::template output<HFT, 2 * DM::HB>(f, x, A.P, A.D, li, L, m, tid, A.ctab, ci, tr);
-  // ---- heads (multimodal_epic.py:187-189): cat[t, f_i, h_i] -> GELU -> out
-  const LDesc c0 = A.D[li], c2 = A.D[li + 1], d0 = A.D[li + 2], d2 = A.D[li + 3];
-  const WRsrc R = weight_rsrc(A.P);
+  for (int i = 0; i < A.nb_fused_exec; ++i) {
+    const int nx = desc_wx(L, i + 1 < A.nb_fused_exec ? li + 4 + 2 : li + 4);
+    EF::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, decltype(t)::v, tid); }, A.use_skip != 0, c, li, ci, nx, ring, tr);
+  }
+  // ---- heads (multimodal_epic.py:187-189): cat[t, f_i, h_i] -> GELU -> out.  Descriptors: output 1, c0, c2, d0, d2
+  const int ic0 = li + 1, id0 = li + 3;
+  EF::template output<HFT, 2 * DM::HB, true>(f, x, c, li, ci, desc_wx(L, which != 1 ? ic0 : id0), ring, tr);
   FE_PROF(L, PF_EPI);
   const int ci_heads = ci;                               // table slots: [.. , continuous head, discrete head]
-  if (which != 1) {
-    ci = ci_heads;
-    const float* cv = time_vec<DM::ET, DM::HB>(A.ctab, ci, A.P + c0.wt, L, tid);
-    AFrag<HBT> pre0;
-    AFrag<1> pre2;
-    mma_prefetch(pre0, R, c0.wx, lane);
-    mma_prefetch(pre2, R, c2.wx, lane);
-    f32x16 h[HBT];
-    acc_init<HBT>(h, m, cv, A.P + c0.b, half);
-    mma_x<HFT, HBT>(h, [&](auto fc) -> f32x16 {
+  if (which != 1)
+    head<DM, RD, CT>(hc, [&](auto fc) -> f32x16 {
       constexpr int t = decltype(fc)::v;
-      if constexpr (t < HBT) return f[t]; else return fetch_tile(S, t - HBT, tid); }, R, c0.wx, lane, pre0);
-    if constexpr (TR::on) tr.template tiles<HBT>(h, half);
-    act_tiles<HBT, MMB_ACT_GELU>(h);
-    if constexpr (TR::on) tr.template tiles<HBT>(h, half);
-    f32x16 o[1];
-    acc_init<1>(o, 0.0f, nullptr, A.P + c2.b, half);
-    mma_x<HBT, 1>(o, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, R, c2.wx, lane, pre2);
-    hc = o[0];
-  }
-  if (which != 0) {
-    ci = ci_heads + 1;
-    const float* cv = time_vec<DM::ET, DM::HB>(A.ctab, ci, A.P + d0.wt, L, tid);
-    AFrag<HBT> pre0;
-    AFrag<1> pre2;
-    mma_prefetch(pre0, R, d0.wx, lane);
-    mma_prefetch(pre2, R, d2.wx, lane);
-    f32x16 h[HBT];
-    acc_init<HBT>(h, m, cv, A.P + d0.b, half);
-    mma_x<HFT, HBT>(h, [&](auto fc) -> f32x16 {
+      if constexpr (t < HBT) return f[t]; else return fetch_tile(S, t - HBT, tid); }, c, ic0, ci_heads,
+      desc_wx(L, which == 2 ? id0 : 0), ring, tr);
+  if (which != 0)
+    head<DM, RD, CT>(hd, [&](auto fc) -> f32x16 {
       constexpr int t = decltype(fc)::v;
-      if constexpr (t < HBT) return f[HBT + t]; else return fetch_tile(S, t, tid); }, R, d0.wx, lane, pre0);
-    if constexpr (TR::on) tr.template tiles<HBT>(h, half);
-    act_tiles<HBT, MMB_ACT_GELU>(h);
-    if constexpr (TR::on) tr.template tiles<HBT>(h, half);
-    f32x16 o[1];
-    acc_init<1>(o, 0.0f, nullptr, A.P + d2.b, half);
-    mma_x<HBT, 1>(o, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, R, d2.wx, lane, pre2);
-    hd = o[0];
-  }
+      if constexpr (t < HBT) return f[HBT + t]; else return fetch_tile(S, t, tid); }, c, id0, ci_heads + 1,
+      desc_wx(L, 0), ring, tr);
   FE_PROF(L, PF_HEAD);
+}
+
+// layer descriptors -> LDS (every stage reads its offsets from there: an LDS broadcast instead of an L2 round trip
+// at the head of every layer)
+__device__ __forceinline__ void load_desc(const FusedArgs& A, Lds& L, int tid) {
+  const int* src = reinterpret_cast<const int*>(A.D);
+  int* dst = reinterpret_cast<int*>(L.desc);
+  for (int i = tid; i < 4 * A.n_desc; i += FE_THREADS) dst[i] = src[i];
 }
 
 template <class DM>
 __device__ __forceinline__ void load_constants(const FusedArgs& A, Lds& L, int tid) {
+  load_desc(A, L, tid);
   for (int i = tid; i < DM::EC * 4; i += FE_THREADS) {
     const int f = i >> 2, d = i & 3;
     L.cw[i] = d < DM::DC ? A.P[A.emb_cw + f * DM::DC + d] : 0.0f;
@@ -399,6 +606,9 @@ fused_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64_t* __
   __shared__ float4 S[DM::HFT * 4 * FE_THREADS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   load_constants<DM>(A, L, tid);
+  __syncthreads();
+  WRing<ring_depth_multi<DM>()> ring;
+  ring_prime(ring, weight_rsrc(A.P), desc_wx(L, 0), lane * 16);
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
     __syncthreads();
     if (tid < DM::ET) L.temb[tid] = temb[(int64_t)b * temb_stride + tid];
@@ -414,7 +624,7 @@ fused_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64_t* __
     __syncthreads();
     f32x16 hc, hd;
     NoTrain nt;
-    forward_jet<DM>(A, L, S, xp, kp, m, which, hc, hd, tid, nt);
+    forward_jet<DM, false>(A, L, S, xp, kp, m, which, hc, hd, tid, ring, nt);
     if (valid && which != 1 && half == 0) {
 #pragma unroll
       for (int d = 0; d < DM::DC; ++d) head_c[gp * DM::DC + d] = hc[d];       // features 0..2 = regs 0..2, half 0
@@ -441,6 +651,9 @@ fused_train_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64
   __shared__ float4 S[DM::HFT * 4 * FE_THREADS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   load_constants<DM>(A, L, tid);
+  __syncthreads();
+  WRing<ring_depth_multi<DM>()> ring;
+  ring_prime(ring, weight_rsrc(A.P), desc_wx(L, 0), lane * 16);
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
     __syncthreads();
     if (tid < DM::ET) L.temb[tid] = temb[(int64_t)b * temb_stride + tid];
@@ -456,7 +669,7 @@ fused_train_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64
     __syncthreads();
     Train tr{slots, n_slots, 0, b, A.N, p, drop_p, seed, offset0};
     f32x16 hc, hd;
-    forward_jet<DM>(A, L, S, xp, kp, m, 2, hc, hd, tid, tr);
+    forward_jet<DM, false>(A, L, S, xp, kp, m, 2, hc, hd, tid, ring, tr);
     if (valid && half == 0) {
 #pragma unroll
       for (int d = 0; d < DM::DC; ++d) head_c[gp * DM::DC + d] = hc[d];
@@ -532,12 +745,16 @@ __global__ void __launch_bounds__(FE_THREADS, 2)
 fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* __restrict__ k) {
   __shared__ Lds L;
   __shared__ float4 S[DM::HFT * 4 * FE_THREADS];
+  __shared__ float park_s[4][FE_THREADS];  // x (3) and k of this lane's particle while a forward runs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   constexpr int V = DM::V;
 #ifdef MMB_FE_PROF
   if (tid == 0) L.tlast = clock64();
 #endif
   load_constants<DM>(A, L, tid);
+  __syncthreads();
+  WRing<ring_depth_multi<DM>()> ring;
+  ring_prime(ring, weight_rsrc(A.P), desc_wx(L, 0), lane * 16);
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
     __syncthreads();
     if (tid == 0) L.cnt = (float)A.counts[b];
@@ -553,25 +770,25 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
       __syncthreads();
       if (tid < DM::ET) L.temb[tid] = Gn.temb_steps[(int64_t)s * DM::ET + tid];
       __syncthreads();
-      A.ctab = Gn.ctab_steps ? Gn.ctab_steps + (int64_t)s * Gn.n_ctab * 128 : nullptr;
+      A.ctab = Gn.ctab_steps + (int64_t)s * Gn.n_ctab * 128;
       const float tt = Gn.times[s];
       f32x16 hc, hd;
       // The particle state is only needed at the two ends of a forward: it waits in LDS meanwhile
       // (each lane reads back its own slot), which keeps it out of the register allocator's way.
       auto park = [&]() {
 #pragma unroll
-        for (int d = 0; d < DM::DC; ++d) L.park[d][tid] = xp[d];
-        L.park[3][tid] = __int_as_float(kp);
+        for (int d = 0; d < DM::DC; ++d) park_s[d][tid] = xp[d];
+        park_s[3][tid] = __int_as_float(kp);
       };
       auto unpark = [&]() {
 #pragma unroll
-        for (int d = 0; d < DM::DC; ++d) xp[d] = L.park[d][tid];
-        kp = __float_as_int(L.park[3][tid]);
+        for (int d = 0; d < DM::DC; ++d) xp[d] = park_s[d][tid];
+        kp = __float_as_int(park_s[3][tid]);
       };
       // Euler step on the drift head (solvers.py:21-25); padded slots move too (K3)
       park();
       NoTrain nt;
-      forward_jet<DM>(A, L, S, xp, kp, m, 0, hc, hd, tid, nt);
+      forward_jet<DM, true>(A, L, S, xp, kp, m, 0, hc, hd, tid, ring, nt);
       unpark();
       {
         float v[3] = {hc[0], hc[1], hc[2]};
@@ -606,7 +823,7 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
       __syncthreads();
       // tau-leap on the logits head, which sees the UPDATED x at the same t (solvers.py:59-81)
       park();
-      forward_jet<DM>(A, L, S, xp, kp, m, 1, hc, hd, tid, nt);
+      forward_jet<DM, true>(A, L, S, xp, kp, m, 1, hc, hd, tid, ring, nt);
       unpark();
       float r[V];
       gather_logits<DM>(hd, r, lane);
@@ -627,11 +844,13 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
 // layer emits the V logits directly (no heads).
 
 // Training (TR = Train) slots: projection 9, layers 8 each (the V logits of the output layer go to the caller).
-template <class DM, class TR>
+template <class DM, bool CT, class TR>
 __device__ __forceinline__ void forward_uni(const FusedArgs& A, Lds& L, float4* S, const float* tab, int kp, float m,
-                                            f32x16& hd, int tid, TR& nt) {
-  constexpr int HT = DM::HT;
+                                            f32x16& hd, int tid, WRing<ring_depth_uni<DM>()>& ring, TR& nt) {
+  constexpr int HT = DM::HT, RD = ring_depth_uni<DM>();
+  typedef Epic<HT, DM::ET, DM::G, RD, CT> E;
   const int lane = tid & 63, half = lane >> 5;
+  FCtx c{A.P, weight_rsrc(A.P), L, m, tid, lane, tid >> 6, half, lane * 16, A.ctab};
   int li = 0, ci = 0;
   FE_PROF(L, PF_STEP);
   f32x16 td[DM::EDT];
@@ -642,16 +861,18 @@ __device__ __forceinline__ void forward_uni(const FusedArgs& A, Lds& L, float4* 
       td[t][4 * q + 2] = truncf(e.z * m); td[t][4 * q + 3] = truncf(e.w * m); }); });
   FE_PROF(L, PF_EMBED);
   f32x16 x[HT];
-  Epic<HT, DM::ET, DM::G>::template project<DM::EDT>(x, [&](auto fc) -> const f32x16& { return td[decltype(fc)::v]; },
-                                                    A.P, A.D, li, L, m, tid, A.ctab, ci, nt);
+  const int nb = A.nb_branch;
+  const int wx_after_proj = desc_wx(L, nb > 0 ? 4 + 2 : 4);
+  E::template project<DM::EDT>(x, [&](auto fc) -> const f32x16& { return td[decltype(fc)::v]; }, c, li, ci, wx_after_proj,
+                               ring, nt);
   if (tid < DM::G) L.gskip[tid] = L.gcur[tid];
   ffor<HT>([&](auto t) { park_tile(S, decltype(t)::v, x[decltype(t)::v], tid); });
-  __syncthreads();
-  for (int i = 0; i < A.nb_branch; ++i)
-    Epic<HT, DM::ET, DM::G>::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, decltype(t)::v, tid); },
-                                   A.use_skip != 0, A.P, A.D, li, L, m, tid, A.ctab, ci, nt);
+  for (int i = 0; i < nb; ++i) {
+    const int nx = desc_wx(L, i + 1 < nb ? li + 4 + 2 : li + 4);
+    E::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, decltype(t)::v, tid); }, A.use_skip != 0, c, li, ci, nx, ring, nt);
+  }
   f32x16 o[1];
-  Epic<HT, DM::ET, DM::G>::template output<1, DM::V>(o, x, A.P, A.D, li, L, m, tid, A.ctab, ci, nt);
+  E::template output<1, DM::V, true>(o, x, c, li, ci, desc_wx(L, 0), ring, nt);
   hd = o[0];
 }
 
@@ -687,6 +908,10 @@ fused_uni_forward_kernel(FusedArgs A, const int64_t* __restrict__ k, const float
   __shared__ __attribute__((aligned(16))) float tab[DM::V * DM::EDP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   load_table_uni<DM>(A, tab, tid);
+  load_desc(A, L, tid);
+  __syncthreads();
+  WRing<ring_depth_uni<DM>()> ring;
+  ring_prime(ring, weight_rsrc(A.P), desc_wx(L, 0), lane * 16);
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
     __syncthreads();
     if (tid < DM::ET) L.temb[tid] = temb[(int64_t)b * temb_stride + tid];
@@ -699,7 +924,7 @@ fused_uni_forward_kernel(FusedArgs A, const int64_t* __restrict__ k, const float
     __syncthreads();
     f32x16 hd;
     NoTrain nt;
-    forward_uni<DM>(A, L, S, tab, kp, m, hd, tid, nt);
+    forward_uni<DM, false>(A, L, S, tab, kp, m, hd, tid, ring, nt);
     float lg[8];
     gather8(hd, lg, lane);
     if (valid && half == 0) {
@@ -721,6 +946,10 @@ fused_uni_train_forward_kernel(FusedArgs A, const int64_t* __restrict__ k, const
   __shared__ __attribute__((aligned(16))) float tab[DM::V * DM::EDP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   load_table_uni<DM>(A, tab, tid);
+  load_desc(A, L, tid);
+  __syncthreads();
+  WRing<ring_depth_uni<DM>()> ring;
+  ring_prime(ring, weight_rsrc(A.P), desc_wx(L, 0), lane * 16);
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
     __syncthreads();
     if (tid < DM::ET) L.temb[tid] = temb[(int64_t)b * temb_stride + tid];
@@ -733,7 +962,7 @@ fused_uni_train_forward_kernel(FusedArgs A, const int64_t* __restrict__ k, const
     __syncthreads();
     Train tr{slots, n_slots, 0, b, A.N, p, drop_p, seed, offset0};
     f32x16 hd;
-    forward_uni<DM>(A, L, S, tab, kp, m, hd, tid, tr);
+    forward_uni<DM, false>(A, L, S, tab, kp, m, hd, tid, ring, tr);
     float lg[8];
     gather8(hd, lg, lane);
     if (valid && half == 0) {
@@ -754,6 +983,10 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
   if (tid == 0) L.tlast = clock64();
 #endif
   load_table_uni<DM>(A, tab, tid);
+  load_desc(A, L, tid);
+  __syncthreads();
+  WRing<ring_depth_uni<DM>()> ring;
+  ring_prime(ring, weight_rsrc(A.P), desc_wx(L, 0), lane * 16);
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
     __syncthreads();
     if (tid == 0) L.cnt = (float)A.counts[b];
@@ -766,10 +999,10 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
       __syncthreads();
       if (tid < DM::ET) L.temb[tid] = Gn.temb_steps[(int64_t)s * DM::ET + tid];
       __syncthreads();
-      A.ctab = Gn.ctab_steps ? Gn.ctab_steps + (int64_t)s * Gn.n_ctab * 128 : nullptr;
+      A.ctab = Gn.ctab_steps + (int64_t)s * Gn.n_ctab * 128;
       f32x16 hd;
       NoTrain nt;
-      forward_uni<DM>(A, L, S, tab, kp, m, hd, tid, nt);
+      forward_uni<DM, true>(A, L, S, tab, kp, m, hd, tid, ring, nt);
       float r[8];
       gather8(hd, r, lane);
       kp = jump_step(r, kp, Gn.times[s], Gn, s == Gn.steps - 1, valid, A.B, A.N, b, p, s, gp);
@@ -781,11 +1014,16 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
 
 
 static int check_fused(const char* name, int B, int N, const void* P, const void* D, const void* maskf,
-                       const void* counts) {
+                       const void* counts, int n_desc) {
   MMB_REQUIRE(B > 0 && N > 0 && N <= 128, "%s: needs 0 < N <= 128 (got B=%d N=%d)", name, B, N);
   MMB_REQUIRE(P && D && maskf && counts, "%s: NULL argument", name);
+  MMB_REQUIRE(n_desc > 0 && n_desc <= MAX_DESC, "%s: %d layer descriptors, the kernels cache at most %d (fewer blocks, "
+              "or the layered path)", name, n_desc, MAX_DESC);
   return MMB_OK;
 }
+// descriptors of a packed model (mmb_hip/fused.py: _pack_multi / _pack_uni): projection 4, EPiC layer 4, output 1, heads 4
+static int n_desc_multi(int nb0, int nb1, int nbf) { return (4 + 4 * nb0 + 1) + (4 + 4 * nb1 + 1) + (4 * nbf + 1) + 4; }
+static int n_desc_uni(int nb) { return 4 + 4 * nb + 1; }
 
 }  // namespace mmb
 
@@ -797,7 +1035,7 @@ extern "C" int mmb_fused_epic_forward(int variant, int B, int N, const float* pa
                                       int off_table, const float* maskf, const int32_t* counts, const float* x,
                                       const int64_t* k, const float* temb, int64_t temb_stride, int which,
                                       float* head_c, float* head_d, void* stream) {
-  int rc = check_fused("mmb_fused_epic_forward", B, N, packed, desc, maskf, counts);
+  int rc = check_fused("mmb_fused_epic_forward", B, N, packed, desc, maskf, counts, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec));
   if (rc) return rc;
   MMB_REQUIRE(variant >= 0 && variant < N_MULTI_VARIANTS, "mmb_fused_epic_forward: unknown variant %d", variant);
   MMB_REQUIRE(x && k && temb, "mmb_fused_epic_forward: NULL state");
@@ -805,7 +1043,7 @@ extern "C" int mmb_fused_epic_forward(int variant, int B, int N, const float* pa
   if (which != 1) MMB_REQUIRE(head_c, "mmb_fused_epic_forward: head_c is NULL");
   if (which != 0) MMB_REQUIRE(head_d, "mmb_fused_epic_forward: head_d is NULL");
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
-              off_table, B, N, maskf, counts, nb_branch1};
+              off_table, B, N, maskf, counts, nb_branch1, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec)};
   const int grid = B < 4096 ? B : 4096;
   switch (variant) {
     case 0: hipLaunchKernelGGL(fused_forward_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k, temb,
@@ -826,7 +1064,7 @@ extern "C" int mmb_fused_epic_train_forward(int variant, int B, int N, const flo
                                             const int64_t* k, const float* temb, int64_t temb_stride,
                                             const void* slots, int n_slots, float drop_p, uint64_t seed,
                                             uint64_t offset0, float* head_c, float* head_d, void* stream) {
-  int rc = check_fused("mmb_fused_epic_train_forward", B, N, packed, desc, maskf, counts);
+  int rc = check_fused("mmb_fused_epic_train_forward", B, N, packed, desc, maskf, counts, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec));
   if (rc) return rc;
   MMB_REQUIRE(variant >= 0 && variant < N_MULTI_VARIANTS, "mmb_fused_epic_train_forward: unknown variant %d", variant);
   MMB_REQUIRE(x && k && temb && head_c && head_d && slots, "mmb_fused_epic_train_forward: NULL argument");
@@ -835,7 +1073,7 @@ extern "C" int mmb_fused_epic_train_forward(int variant, int B, int N, const flo
   MMB_REQUIRE(n_slots == expect, "mmb_fused_epic_train_forward: %d save slots given, the architecture has %d", n_slots,
               expect);
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
-              off_table, B, N, maskf, counts, nb_branch1};
+              off_table, B, N, maskf, counts, nb_branch1, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec)};
   const SaveSlot* tab = reinterpret_cast<const SaveSlot*>(slots);
   const int grid = B < 4096 ? B : 4096;
   switch (variant) {
@@ -856,12 +1094,12 @@ extern "C" int mmb_fused_uni_forward(int variant, int B, int N, const float* pac
                                      int num_blocks, int use_skip, int off_table, const float* maskf,
                                      const int32_t* counts, const int64_t* k, const float* temb, int64_t temb_stride,
                                      float* head_d, void* stream) {
-  int rc = check_fused("mmb_fused_uni_forward", B, N, packed, desc, maskf, counts);
+  int rc = check_fused("mmb_fused_uni_forward", B, N, packed, desc, maskf, counts, n_desc_uni(num_blocks));
   if (rc) return rc;
   MMB_REQUIRE(variant >= 0 && variant < N_UNI_VARIANTS, "mmb_fused_uni_forward: unknown variant %d", variant);
   MMB_REQUIRE(k && temb && head_d, "mmb_fused_uni_forward: NULL state");
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), num_blocks, 0, use_skip, 0, 0, off_table, B, N,
-              maskf, counts};
+              maskf, counts, 0, n_desc_uni(num_blocks)};
   const int grid = B < 4096 ? B : 4096;
   switch (variant) {
     case 0: hipLaunchKernelGGL(fused_uni_forward_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k, temb,
@@ -881,7 +1119,7 @@ extern "C" int mmb_fused_uni_train_forward(int variant, int B, int N, const floa
                                            const int32_t* counts, const int64_t* k, const float* temb,
                                            int64_t temb_stride, const void* slots, int n_slots, float drop_p,
                                            uint64_t seed, uint64_t offset0, float* head_d, void* stream) {
-  int rc = check_fused("mmb_fused_uni_train_forward", B, N, packed, desc, maskf, counts);
+  int rc = check_fused("mmb_fused_uni_train_forward", B, N, packed, desc, maskf, counts, n_desc_uni(num_blocks));
   if (rc) return rc;
   MMB_REQUIRE(variant >= 0 && variant < N_UNI_VARIANTS, "mmb_fused_uni_train_forward: unknown variant %d", variant);
   MMB_REQUIRE(k && temb && head_d && slots, "mmb_fused_uni_train_forward: NULL argument");
@@ -890,7 +1128,7 @@ extern "C" int mmb_fused_uni_train_forward(int variant, int B, int N, const floa
   MMB_REQUIRE(n_slots == expect, "mmb_fused_uni_train_forward: %d save slots given, the architecture has %d", n_slots,
               expect);
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), num_blocks, 0, use_skip, 0, 0, off_table, B, N,
-              maskf, counts};
+              maskf, counts, 0, n_desc_uni(num_blocks)};
   const SaveSlot* tab = reinterpret_cast<const SaveSlot*>(slots);
   const int grid = B < 4096 ? B : 4096;
   switch (variant) {
@@ -912,13 +1150,14 @@ extern "C" int mmb_fused_uni_generate(int variant, int B, int N, const float* pa
                                       const float* temb_steps, const float* ctab_steps, int n_ctab, float dt,
                                       int thermo_kind, float gamma, const float* delta_n, uint64_t seed,
                                       uint64_t offset, void* stream) {
-  int rc = check_fused("mmb_fused_uni_generate", B, N, packed, desc, maskf, counts);
+  int rc = check_fused("mmb_fused_uni_generate", B, N, packed, desc, maskf, counts, n_desc_uni(num_blocks));
   if (rc) return rc;
   MMB_REQUIRE(variant >= 0 && variant < N_UNI_VARIANTS, "mmb_fused_uni_generate: unknown variant %d", variant);
   MMB_REQUIRE(k && times && temb_steps && steps > 0, "mmb_fused_uni_generate: NULL state / steps");
+  MMB_REQUIRE(ctab_steps && n_ctab > 0, "mmb_fused_uni_generate: the per-grid-point time-vector table is required");
   MMB_REQUIRE(thermo_kind >= 0 && thermo_kind <= 4, "mmb_fused_uni_generate: bad thermostat");
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), num_blocks, 0, use_skip, 0, 0, off_table, B, N,
-              maskf, counts};
+              maskf, counts, 0, n_desc_uni(num_blocks)};
   GenArgs Gn{steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, (float)(-(double)8 * (double)gamma), delta_n,
              seed, offset, 0, 0.0f, nullptr};
   const int grid = B < 4096 ? B : 4096;
@@ -1105,12 +1344,11 @@ extern "C" int mmb_toy_generate(int B, int N, int H, int Dc, int V, const float*
              em, em_sigma, delta_w};
   constexpr int HH = 64;
   const size_t lds = (size_t)(HH * 33 + 3 * HH * (HH + 1) + 32 * (HH + 1) + 4 * HH + 32 + 8 * (HH / 4)) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    MMB_REQUIRE(hipFuncSetAttribute((const void*)toy_generate_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds) == hipSuccess, "mmb_toy_generate: cannot raise the dynamic LDS limit");
-    attr_set = true;
-  }
+  static PerDeviceOnce lds_limit;                        // the runtime keeps the attribute per device
+  MMB_REQUIRE(lds_limit.run([&] {
+                return hipFuncSetAttribute((const void*)toy_generate_kernel<64, 2>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess; }),
+              "mmb_toy_generate: cannot raise the dynamic LDS limit");
   const int64_t tiles = ((int64_t)B * N + 31) / 32;
   const int64_t blocks = (tiles + 3) / 4;
   hipLaunchKernelGGL((toy_generate_kernel<64, 2>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), lds,
@@ -1135,13 +1373,14 @@ extern "C" int mmb_fused_epic_generate(int variant, int B, int N, const float* p
                                        const float* ctab_steps, int n_ctab, float dt,
                                        int thermo_kind, float gamma, const float* delta_n, uint64_t seed,
                                        uint64_t offset, int em, float em_sigma, const float* delta_w, void* stream) {
-  int rc = check_fused("mmb_fused_epic_generate", B, N, packed, desc, maskf, counts);
+  int rc = check_fused("mmb_fused_epic_generate", B, N, packed, desc, maskf, counts, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec));
   if (rc) return rc;
   MMB_REQUIRE(variant >= 0 && variant < N_MULTI_VARIANTS, "mmb_fused_epic_generate: unknown variant %d", variant);
   MMB_REQUIRE(x && k && times && temb_steps && steps > 0, "mmb_fused_epic_generate: NULL state / steps");
+  MMB_REQUIRE(ctab_steps && n_ctab > 0, "mmb_fused_epic_generate: the per-grid-point time-vector table is required");
   MMB_REQUIRE(thermo_kind >= 0 && thermo_kind <= 4, "mmb_fused_epic_generate: bad thermostat");
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
-              off_table, B, N, maskf, counts, nb_branch1};
+              off_table, B, N, maskf, counts, nb_branch1, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec)};
   GenArgs Gn{steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, (float)(-(double)8 * (double)gamma), delta_n, seed, offset,
              em, em_sigma, delta_w};
   const int grid = B < 4096 ? B : 4096;

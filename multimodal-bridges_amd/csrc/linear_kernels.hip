@@ -1136,13 +1136,11 @@ static int linear_cat_impl(int M, int rows_per_jet, int n_seg, const void* const
       dim3 g3(gx, gy);
 #define MMB_STREAM(KERNEL, THREADS_)                                                                             \
   do {                                                                                                           \
-    static bool attr_set = false;                                                                                \
-    if (!attr_set) {                                                                                             \
-      MMB_REQUIRE(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize,           \
-                                      160 * 1024) == hipSuccess,                                                 \
-                  "mmb_linear_cat: cannot raise the dynamic LDS limit");                                         \
-      attr_set = true;                                                                                           \
-    }                                                                                                            \
+    static PerDeviceOnce lds_limit;          /* per instantiation AND per device (the runtime keeps it per device) */ \
+    MMB_REQUIRE(lds_limit.run([&] {                                                                              \
+                  return hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                             160 * 1024) == hipSuccess; }),                                      \
+                "mmb_linear_cat: cannot raise the dynamic LDS limit");                                           \
     hipLaunchKernelGGL(KERNEL, g3, dim3(THREADS_), lds, st, M, rows_per_jet, sg, K, maskf, W, w_ld, bias, Nout,  \
                        act, residual, res_ld, row_scale, Y, y_ld, pre_act, post);                                \
   } while (0)

@@ -350,8 +350,10 @@ extern "C" int mmb_loss_fwd_bwd(int B, int N, int Dc, int V, const float* head_c
   const bool v8 = head_d && V == 8 && ((reinterpret_cast<uintptr_t>(head_d) & 15) == 0) &&
                   (!d_head_d || (reinterpret_cast<uintptr_t>(d_head_d) & 15) == 0);
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  // the flat-array kernel indexes float4 number i of the (P*3) arrays in 32 bits (4*i wraps at P >= 2^30) and finds the
+  // jet of a particle by a float estimate +-1 (exact below 2^24 jets): beyond either, the per-particle kernel
   const bool fast = v8 && head_c && Dc == 3 && P % 4 == 0 && al16(head_c) && al16(xt) && al16(x0) && al16(x1) &&
-                    (!d_head_c || al16(d_head_c));
+                    (!d_head_c || al16(d_head_c)) && P < (1 << 30) && B < (1 << 24);
   if (fast)
     hipLaunchKernelGGL(loss_kernel_fast, dim3(grid), dim3(256), 0, as_stream(stream), P, N,
                        reinterpret_cast<const float4*>(head_c), reinterpret_cast<const float4*>(head_d), t,

@@ -490,43 +490,89 @@ __device__ __forceinline__ void split_half(const f32x16& xt, bf16x8& h, bf16x8& 
                       xt[8 * JJ + 4], xt[8 * JJ + 5], xt[8 * JJ + 6], xt[8 * JJ + 7]};
   split8(v, h, m, l);
 }
+// The three planes of one B operand (16 k-values x this lane's particle) as dwords: pair j holds values 2j, 2j+1
+struct Planes {
+  uint32_t h[4], m[4], l[4];
+};
+// pair J of k-block JJ of tile xt -> dword J of each plane (11 vector instructions)
+template <int JJ, int J>
+__device__ __forceinline__ void split_pair(const f32x16& xt, Planes& p) {
+  const float a = xt[8 * JJ + 2 * J], b = xt[8 * JJ + 2 * J + 1];
+  p.h[J] = pk_bf16(a, b);
+  const float ra = a - __builtin_bit_cast(float, p.h[J] << 16), rb = b - __builtin_bit_cast(float, p.h[J] & 0xFFFF0000u);
+  p.m[J] = pk_bf16(ra, rb);
+  const float sa = ra - __builtin_bit_cast(float, p.m[J] << 16), sb = rb - __builtin_bit_cast(float, p.m[J] & 0xFFFF0000u);
+  p.l[J] = pk_bf16(sa, sb);
+}
+__device__ __forceinline__ bf16x8 plane_of(const uint32_t (&d)[4]) {
+  typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+  const u32x4v v = {d[0], d[1], d[2], d[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// One GEMM of the forward stream.  Software pipeline, pinned: while the six MFMAs of step (k-block kb, output tile ot)
+// run, the wave splits its share of k-block kb+1 (4/OT pairs, 11 vector instructions each) and the ring slot is
+// refilled.  sched_group_barrier writes the issue order down -- ONE MFMA, then the vector instructions that fit under
+// it -- because the six MFMAs of a step depend on each other through the accumulator: in program order "6 MFMAs, then
+// the split" (what the scheduler emits on its own) the wave sits on the matrix pipe for 6 x 32 cycles with nothing to
+// issue and does the 44 instructions of the split afterwards with the pipe idle (SQ_VALU_MFMA_COEXEC_CYCLES was 11 %
+// of the MFMA-busy cycles: the two pipes took turns).
 template <int KT, int OT, int RD, bool PF, typename TileFn>
 __device__ __forceinline__ void mma_r(f32x16 (&acc)[OT], TileFn&& tile, WRsrc R, int woff, int next_woff, int lane16,
                                       WRing<RD>& ring) {
-  constexpr int NG = KT * 2 * OT;
+  constexpr int KB = KT * 2, NG = KB * OT;
   static_assert(NG % RD == 0 && NG >= RD, "every GEMM must be a whole number of ring turns");
+  static_assert(OT == 1 || OT == 2 || OT == 4, "mma_r: 1, 2 or 4 output tiles");
 #ifdef MMB_WHATIF_NOGEMM          // developer timing build (wrong results on purpose): what the forward costs without its GEMMs
   return;
 #endif
-  ffor<KT>([&](auto fc) {
-    constexpr int ft = decltype(fc)::v;
-    decltype(auto) xt = tile(IF<ft>{});
-    ffor<2>([&](auto jc) {
-      constexpr int jj = decltype(jc)::v;
-      bf16x8 bh, bm, bl;
-      split_half<jj>(xt, bh, bm, bl);
-      ffor<OT>([&](auto oc) {
-        constexpr int ot = decltype(oc)::v;
-        constexpr int g = (ft * 2 + jj) * OT + ot;
-        constexpr int cur = g % RD;
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, ring.s[cur].p[0]), am = __builtin_bit_cast(bf16x8, ring.s[cur].p[1]),
-                     al = __builtin_bit_cast(bf16x8, ring.s[cur].p[2]);
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[ot], 0, 0, 0);
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[ot], 0, 0, 0);
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[ot], 0, 0, 0);
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[ot], 0, 0, 0);
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[ot], 0, 0, 0);
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[ot], 0, 0, 0);
-        if constexpr (g + RD < NG) {
-          frag_load(ring.s[cur], R, woff, g + RD, lane16);
-        } else if constexpr (PF) {               // no run-time condition here: a branch in the stream makes the
-          frag_load(ring.s[cur], R, next_woff, g + RD - NG, lane16);       // wait-count pass drain the queue at the join
-        }
-        // nothing crosses: without it the scheduler sinks the refill to its first use under register pressure (load,
-        // vmcnt(0), MFMA -- the ring undone)
-        __builtin_amdgcn_sched_barrier(0);
-      });
+  constexpr int PP = 4 / OT;                   // pairs of the next k-block split per step
+  Planes cur, nxt;
+  {
+    decltype(auto) x0 = tile(IF<0>{});
+    split_pair<0, 0>(x0, cur); split_pair<0, 1>(x0, cur); split_pair<0, 2>(x0, cur); split_pair<0, 3>(x0, cur);
+  }
+  ffor<KB>([&](auto kc) {
+    constexpr int kb = decltype(kc)::v;
+    constexpr bool more = kb + 1 < KB;
+    const bf16x8 bh = plane_of(cur.h), bm = plane_of(cur.m), bl = plane_of(cur.l);
+    ffor<OT>([&](auto oc) {
+      constexpr int ot = decltype(oc)::v;
+      constexpr int g = kb * OT + ot;
+      constexpr int slot = g % RD;
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, ring.s[slot].p[0]), am = __builtin_bit_cast(bf16x8, ring.s[slot].p[1]),
+                   al = __builtin_bit_cast(bf16x8, ring.s[slot].p[2]);
+      acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[ot], 0, 0, 0);
+      acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[ot], 0, 0, 0);
+      acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[ot], 0, 0, 0);
+      acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[ot], 0, 0, 0);
+      acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[ot], 0, 0, 0);
+      acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[ot], 0, 0, 0);
+      if constexpr (more) {
+        decltype(auto) xn = tile(IF<(kb + 1) / 2>{});
+        ffor<PP>([&](auto pc) { split_pair<(kb + 1) % 2, ot * PP + decltype(pc)::v>(xn, nxt); });
+      }
+      if constexpr (g + RD < NG) {
+        frag_load(ring.s[slot], R, woff, g + RD, lane16);
+      } else if constexpr (PF) {               // no run-time condition here: a branch in the stream makes the
+        frag_load(ring.s[slot], R, next_woff, g + RD - NG, lane16);       // wait-count pass drain the queue at the join
+      }
+      // issue order of the step: MFMA, vector instructions under it, ... ; then the refill
+      if constexpr (more) {
+        constexpr int NV = 11 * PP, per = (NV + 5) / 6;
+        ffor<6>([&](auto) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+        });
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+      // nothing crosses: without it the scheduler sinks the refill to its first use under register pressure (load,
+      // vmcnt(0), MFMA -- the ring undone)
+      __builtin_amdgcn_sched_barrier(0);
     });
+    if constexpr (more) cur = nxt;
   });
 }
 

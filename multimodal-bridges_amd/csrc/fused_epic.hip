@@ -27,6 +27,7 @@
 // accumulator's initial value.  One jet's matvec latency then hides under the other jet's MFMAs.
 
 #include "fused_common.h"
+#include <stdlib.h>
 
 namespace mmb {
 
@@ -397,7 +398,24 @@ struct GenArgs {
   int em;                    // 1: Euler-Maruyama  x += dt v + sigma sqrt(t(1-t)) dW  (solvers.py:27-33, no sqrt(dt))
   float em_sigma;
   const float* delta_w;      // (steps,B,N,DC) injected Wiener increments or NULL -> Philox/Box-Muller
+  int stagger;               // core-clock cycles the second workgroup of a CU waits before its first forward (0: none)
 };
+
+// Two jets share a CU and run the SAME program: started together they stay in lock-step -- both in their GEMMs
+// (one matrix pipe per SIMD: half speed each), then both in their per-jet chains (pipe idle).  The workgroup that
+// finds itself in the second wave slot of its SIMD (HW_ID.wave_id of its first wave) starts `stagger` cycles late, so
+// that one jet's chain falls under the other's GEMMs; only workgroups of the first dispatch round wait (later ones
+// inherit the offset: they start when their predecessor ends).
+__device__ __forceinline__ void stagger_start(int cycles, int tid, int* flag) {
+  if (cycles <= 0 || blockIdx.x >= 512) return;
+  if (tid == 0) *flag = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xF);      // HW_REG_HW_ID: wave_id[3:0]
+  __syncthreads();
+  if ((*flag & 1) != 0) {
+    const long long t0 = clock64();
+    while (clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(16);
+  }
+  __syncthreads();
+}
 
 
 struct FusedArgs {
@@ -746,6 +764,7 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
   __shared__ Lds L;
   __shared__ float4 S[DM::HFT * 4 * FE_THREADS];
   __shared__ float park_s[4][FE_THREADS];  // x (3) and k of this lane's particle while a forward runs
+  stagger_start(Gn.stagger, threadIdx.x, L.red);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   constexpr int V = DM::V;
 #ifdef MMB_FE_PROF
@@ -978,6 +997,7 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
   __shared__ Lds L;
   __shared__ float4 S[DM::HT * 4 * FE_THREADS];
   __shared__ __attribute__((aligned(16))) float tab[DM::V * DM::EDP];
+  stagger_start(Gn.stagger, threadIdx.x, L.red);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
 #ifdef MMB_FE_PROF
   if (tid == 0) L.tlast = clock64();
@@ -1013,6 +1033,11 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
 
 
 
+// MMB_STAGGER=<cycles> (developer switch; default: see stagger_default) -- start offset of the second jet of a CU
+static int stagger_cycles(int dflt) {
+  const char* e = getenv("MMB_STAGGER");
+  return e ? atoi(e) : dflt;
+}
 static int check_fused(const char* name, int B, int N, const void* P, const void* D, const void* maskf,
                        const void* counts, int n_desc) {
   MMB_REQUIRE(B > 0 && N > 0 && N <= 128, "%s: needs 0 < N <= 128 (got B=%d N=%d)", name, B, N);
@@ -1159,7 +1184,7 @@ extern "C" int mmb_fused_uni_generate(int variant, int B, int N, const float* pa
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), num_blocks, 0, use_skip, 0, 0, off_table, B, N,
               maskf, counts, 0, n_desc_uni(num_blocks)};
   GenArgs Gn{steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, (float)(-(double)8 * (double)gamma), delta_n,
-             seed, offset, 0, 0.0f, nullptr};
+             seed, offset, 0, 0.0f, nullptr, stagger_cycles(0)};
   const int grid = B < 4096 ? B : 4096;
   switch (variant) {
     case 0: hipLaunchKernelGGL(fused_uni_generate_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k); break;
@@ -1341,7 +1366,7 @@ extern "C" int mmb_toy_generate(int B, int N, int H, int Dc, int V, const float*
   ToyW W{table, weights[0], weights[1], weights[2], weights[3], weights[4], weights[5], weights[6], weights[7],
          weights[8], weights[9], weights[10], weights[11]};
   GenArgs Gn{steps, times, nullptr, nullptr, 0, dt, thermo_kind, (float)(-(double)V * (double)gamma), delta_n, seed, offset,
-             em, em_sigma, delta_w};
+             em, em_sigma, delta_w, 0};
   constexpr int HH = 64;
   const size_t lds = (size_t)(HH * 33 + 3 * HH * (HH + 1) + 32 * (HH + 1) + 4 * HH + 32 + 8 * (HH / 4)) * sizeof(float);
   static PerDeviceOnce lds_limit;                        // the runtime keeps the attribute per device
@@ -1382,7 +1407,7 @@ extern "C" int mmb_fused_epic_generate(int variant, int B, int N, const float* p
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
               off_table, B, N, maskf, counts, nb_branch1, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec)};
   GenArgs Gn{steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, (float)(-(double)8 * (double)gamma), delta_n, seed, offset,
-             em, em_sigma, delta_w};
+             em, em_sigma, delta_w, stagger_cycles(0)};
   const int grid = B < 4096 ? B : 4096;
   switch (variant) {
     case 0: hipLaunchKernelGGL(fused_generate_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k); break;

@@ -102,7 +102,7 @@ def profile_dominant_kernel(model, config, B, device, passes=3):
     return groups
 
 
-TRAFFIC_FILES = ("profiles/r2/pmc_traffic.json", "profiles/r1/pmc_traffic.json")
+TRAFFIC_FILES = ("profiles/r3/pmc_traffic.json", "profiles/r2/pmc_traffic.json", "profiles/r1/pmc_traffic.json")
 
 
 def measured_traffic(workload):
@@ -118,6 +118,39 @@ def measured_traffic(workload):
         except (OSError, ValueError):
             continue
     return None, None
+
+
+def training_roofline(model, config, workload, B, training):
+    """Both bounds of the training step (forward + reverse + weight gradients of the set encoder): algorithmic GEMM
+    flops (3 x the forward's: fwd, dX, dW) / step time against the native fp32 and -- for the flops the kernels
+    execute as six bf16 products -- the bf16 MFMA peak; HBM bytes of the step (rocprofv3 PMC passes of this
+    command, B = 1024) / step time against 8 TB/s.  The step is bounded by neither: see DESIGN.md."""
+    sec = training["ms_per_step"] * 1e-3
+    P = B * config.data.max_num_particles
+    out = {"unit": "per rank and step", "ms_per_step": training["ms_per_step"]}
+    try:
+        from mmb_hip.fused import algorithmic_flops_per_particle
+        fpp = float(algorithmic_flops_per_particle(model))
+        alg = 3.0 * fpp * P / sec / 1e12
+        out["mfma"] = {"algorithmic_fp32_tflops": alg, "frac_of_native_fp32_mfma_peak": alg / PEAK_FP32_MFMA_TFLOPS,
+                       "peak_fp32": PEAK_FP32_MFMA_TFLOPS, "flops_per_particle_fwd": fpp, "passes": 3}
+        pack = model._fused_pack() if hasattr(model, "_fused_pack") else None
+        if pack and pack.get("mfma_flops_per_forward"):
+            ex = 6.0 * 3.0 * float(pack["mfma_flops_per_forward"]) * P / sec / 1e12
+            out["mfma"].update({"executed_bf16_tflops": ex, "frac_of_bf16_mfma_peak": ex / PEAK_BF16_MFMA_TFLOPS,
+                                "peak_bf16": PEAK_BF16_MFMA_TFLOPS})
+    except Exception as exc:                                   # encoders without a flop model (transformer, toy)
+        out["mfma"] = {"note": f"no flop model for this encoder ({type(exc).__name__})"}
+    tr_step, src = measured_traffic("training_step")
+    tr_step = (tr_step or {}).get(workload)
+    if tr_step and B == 1024:                                  # PMC passes were taken at 1024 jets per rank and step
+        by = tr_step["bytes_per_step"]
+        out["hbm"] = {"traffic_bytes": by, "achieved_gbs": by / sec / 1e9, "peak_gbs": PEAK_HBM_GBS,
+                      "frac": by / sec / 1e9 / PEAK_HBM_GBS, "traffic_source": src}
+    else:
+        out["hbm"] = None
+    out["bound"] = "hbm" if out.get("hbm") else "mfma"
+    return out
 
 
 def cpu_baseline(model, config, workload, n_jets, n_steps):
@@ -349,14 +382,17 @@ def main():
                     "share_of_gpu_time": tz["ms"] / total_ms}
         elif dom:
             achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            # the per-particle layers run linear_stream_x6_kernel: every fp32 product as six bf16 MFMA products
-            # (6 executed bf16 flops per algorithmic fp32 flop), priced against the dense bf16 peak like the fused kernels
-            roof = {"kernel": "linear_stream_x6_kernel (per-particle layers, row streaming; fp32 products as 6 x "
-                              "v_mfma_f32_32x32x16_bf16 over a 3-plane exact operand split)", "bound": "mfma",
-                    "achieved": 6 * achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": 6 * achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
-                    "algorithmic_fp32_tflops": achieved,
-                    "algorithmic_frac_of_native_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+            # the group holds every per-particle mmb_linear_cat launch: most run linear_stream_x6_kernel (fp32 products
+            # as six bf16 MFMA products), unaligned first layers the tiled fp32-MFMA kernel, and MMB_LINEAR_PATH can
+            # force either -- so `achieved` is the ALGORITHMIC fp32 rate against the native fp32 MFMA peak, and the
+            # bf16 figure (valid only for the x6 launches) is a separate, labelled estimate
+            roof = {"kernel": "mmb_linear_cat, per-particle layers (linear_stream_x6_kernel for aligned widths, tiled "
+                              "fp32-MFMA kernel otherwise)", "bound": "mfma",
+                    "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                    "linear_path": os.environ.get("MMB_LINEAR_PATH", "auto"),
+                    "x6_estimate_bf16_tflops_if_all_launches_ran_x6": 6 * achieved,
+                    "x6_estimate_frac_of_bf16_peak": 6 * achieved / PEAK_BF16_MFMA_TFLOPS,
                     "launches": dom["n"], "avg_launch_us": dom["ms"] * 1e3 / dom["n"],
                     "share_of_gpu_time": dom["ms"] / total_ms}
         line = {
@@ -373,11 +409,8 @@ def main():
             "kernel_time_ms": {k: round(v["ms"], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])},
         }
         if training is not None:
-            tr_step = (measured_traffic("training_step")[0] or {}).get(args.workload)
-            if tr_step and B == 1024:                       # PMC passes were taken at 1024 jets per rank and step
-                per_rank = tr_step["bytes_per_step"]
-                training["hbm_traffic_bytes_per_rank_step"] = per_rank
-                training["hbm_frac"] = per_rank / (training["ms_per_step"] * 1e-3) / 8.0e12
+            if "ms_per_step" in training:
+                training["roofline"] = training_roofline(model, config, args.workload, B, training)
             line["training"] = training
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, config, args.workload, args.cpu_jets, args.cpu_steps)

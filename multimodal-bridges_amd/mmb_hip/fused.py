@@ -633,7 +633,9 @@ def generate(pack, mi, x, k, times, temb_steps, dt, thermo_kind, gamma, delta_n=
     """In-place generation loop on x (B,N,3) and k (B,N,1).  em_sigma is None -> Euler, else
     Euler-Maruyama with sigma_t = em_sigma*sqrt(t(1-t)) and increments delta_w (steps,B,N,3) | Philox."""
     B, N = mi.B, mi.N
-    n_ctab = 0 if ctab is None else ctab.shape[1]
+    if ctab is None:                       # the kernels take the per-step time vectors from this table only
+        ctab = time_vector_table(pack, temb_steps)
+    n_ctab = ctab.shape[1]
     call("mmb_fused_epic_generate", pack["variant"], B, N, f32(pack["packed"]), i32(pack["desc"]), pack["nb_branch"],
          pack["nb_branch1"], pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"], pack["off_table"],
          f32(mi.maskf), i32(mi.counts), f32(x, "x"), i64(k, "k"), times.numel(), f32(times, "times"), f32(temb_steps, "temb_steps"),
@@ -655,7 +657,9 @@ def forward_uni(pack, mi, k, temb, temb_stride=None):
 def generate_uni(pack, mi, k, times, temb_steps, dt, thermo_kind, gamma, delta_n=None, seed=0, offset=0, ctab=None):
     """In-place discrete-only generation loop on k (B,N,1)."""
     B, N = mi.B, mi.N
-    n_ctab = 0 if ctab is None else ctab.shape[1]
+    if ctab is None:
+        ctab = time_vector_table(pack, temb_steps)
+    n_ctab = ctab.shape[1]
     call("mmb_fused_uni_generate", pack["variant"], B, N, f32(pack["packed"]), i32(pack["desc"]), pack["num_blocks"],
          pack["use_skip"], pack["off_table"], f32(mi.maskf), i32(mi.counts), i64(k, "k"), times.numel(),
          f32(times, "times"), f32(temb_steps, "temb_steps"), f32(ctab, "ctab"), n_ctab, _fl(dt), thermo_kind,

@@ -15,6 +15,7 @@ the global-norm clip runs on the already averaged buffer.
 """
 import json
 import os
+import inspect
 import time
 from typing import Optional
 
@@ -93,6 +94,33 @@ def optimizer_step(opt, flat, max_norm):
         opt.step()
 
 
+def _staged(dist, t):
+    """gloo moves host memory only (the two-ranks-on-one-GPU rehearsal; RCCL refuses two ranks on one device): device
+    tensors of the small control-plane collectives go through the host then."""
+    return dist.get_backend() == "gloo" and t.is_cuda
+
+
+def all_reduce_(dist, t, op=None):
+    op = dist.ReduceOp.SUM if op is None else op
+    if _staged(dist, t):
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
+def broadcast_(dist, t, src=0):
+    if _staged(dist, t):
+        h = t.cpu()
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
+    return t
+
+
 def gather_generated(gen, dist, rank, world):
     """ONE tensor gather of the generated shards to rank 0 (the reference concatenates per-rank files,
     callbacks_generator.py:53-70).  x (J,N,Dc) f32, k (J,N,1), mask (J,N,1) are packed into one (Jmax, N, Dc+2) f32
@@ -102,7 +130,7 @@ def gather_generated(gen, dist, rank, world):
     J, N = gen.mask.shape[0], gen.mask.shape[1]
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
     counts[rank] = J
-    dist.all_reduce(counts)
+    all_reduce_(dist, counts)
     jmax = int(counts.max())
     has_c, has_d = gen.has_continuous, gen.has_discrete
     Dc = gen.continuous.shape[-1] if has_c else 0
@@ -182,7 +210,7 @@ class ExperimentPipeline:
             self.model._calls = int(self._resume["philox_calls"])          # resumed epochs draw NEW noise streams
         if self.dist is not None:                                  # identical initial weights on every rank
             for p in self.model.parameters():
-                self.dist.broadcast(p.data, src=0)
+                broadcast_(self.dist, p.data, src=0)
         self.datamodule = datamodule_cls(self.config) if datamodule_cls is not None else None
         self.history = []
 
@@ -218,7 +246,7 @@ class ExperimentPipeline:
         if self.dist is None:
             return n
         t = torch.tensor([n], dtype=torch.int64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        all_reduce_(self.dist, t, op=self.dist.ReduceOp.MIN)
         return int(t.item())
 
     def train(self):
@@ -238,9 +266,9 @@ class ExperimentPipeline:
             model.train()
             acc = torch.zeros(3, device=self.device)
             n = 0
-            try:
+            if "epoch" in inspect.signature(self.datamodule.train_dataloader).parameters:
                 loader = self.datamodule.train_dataloader(epoch=epoch)      # reshuffled every epoch (shuffle=True upstream)
-            except TypeError:
+            else:
                 loader = self.datamodule.train_dataloader()
             batches = list(loader) if not hasattr(loader, "__len__") else loader
             # every step ends in a collective: all ranks must run the SAME number of steps (shards differ by a jet)
@@ -265,7 +293,7 @@ class ExperimentPipeline:
                 nv += 1
             stats = torch.cat([acc / max(n, 1), val / max(nv, 1)])
             if self.dist is not None:
-                self.dist.all_reduce(stats)
+                all_reduce_(self.dist, stats)
                 stats /= self.world
             tl, tc, td, vl = [float(v) for v in stats.tolist()]       # one host sync per EPOCH
             self._log({"epoch": epoch, "train_loss": tl, "train_loss_continuous": tc, "train_loss_discrete": td,
@@ -347,12 +375,39 @@ def bench_training(model, config, B, device, dist, steps=10, warmup=3):
     dt = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        all_reduce_(dist, tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # untimed extra steps with device events between the phases (one stream: the events split the step exactly), and
+    # with every C-ABI call bracketed (mmb_hip.PROFILE) -- what a weak scaling curve is diagnosed with
+    import mmb_hip
+    n_ph = 5
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_ph)]
+    for j in range(n_ph):
+        flat.zero()
+        ev[j][0].record()
+        batch = DataCoupling(TensorMultiModal(), TensorMultiModal(None, tgt.continuous, tgt.discrete, tgt.mask), None)
+        model.training_step(batch, steps + j)["loss"].backward()
+        ev[j][1].record()
+        flat.all_reduce_mean(dist, world)
+        ev[j][2].record()
+        optimizer_step(opt, flat, config.trainer.gradient_clip_val)
+        ev[j][3].record()
+    torch.cuda.synchronize()
+    ph = [sum(e[i].elapsed_time(e[i + 1]) for e in ev) / n_ph for i in range(3)]
+    mmb_hip.PROFILE = []
+    for j in range(3):
+        step(steps + n_ph + j)
+    torch.cuda.synchronize()
+    rec, mmb_hip.PROFILE = mmb_hip.PROFILE, None
+    kern = {}
+    for name, _, e0, e1 in rec:
+        kern[name] = kern.get(name, 0.0) + e0.elapsed_time(e1) / 3
     model.train(was_training)
     for p in model.parameters():
         p.grad = None
     return {"value": B * world * steps / dt, "unit": "jets/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "global_batch": B * world, "dropout": config.encoder.dropout, "final_loss": float(loss.detach()),
             "optimizer": type(opt).__name__,
-            "includes": "bridge sampling, fwd, loss, bwd, grad all-reduce, clip, AdamW"}
+            "includes": "bridge sampling, fwd, loss, bwd, grad all-reduce, clip, AdamW",
+            "fwd_loss_bwd_ms": ph[0], "allreduce_ms": ph[1], "optimizer_ms": ph[2],
+            "entry_point_ms_per_step": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}}

@@ -32,10 +32,12 @@ def unused_parameter_names(model):
 
 class FlatAdamW(torch.optim.Optimizer):
     def __init__(self, named_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False,
-                 unused=()):
-        if amsgrad:
-            raise ValueError("FlatAdamW: amsgrad is not implemented (no reference config uses it)")
+                 unused=(), maximize=False, foreach=None, fused=None, capturable=False, differentiable=False):
+        # foreach / fused / capturable pick torch's implementation, not the update rule: accepted and ignored
+        if amsgrad or maximize or differentiable:
+            raise ValueError("FlatAdamW: amsgrad / maximize / differentiable are not implemented (no reference config uses them)")
         named = [(n, p) for n, p in named_params if p.requires_grad]
+        self._model_order = [n for n, _ in named]
         unused = set(unused)
         order = [(n, p) for n, p in named if n not in unused] + [(n, p) for n, p in named if n in unused]
         params = [p for _, p in order]
@@ -101,10 +103,54 @@ class FlatAdamW(torch.optim.Optimizer):
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
-        if not sd.get("flat_adamw") or list(sd["names"]) != list(self.names):
-            raise ValueError("FlatAdamW.load_state_dict: checkpoint was not written by FlatAdamW for this model")
-        self.t = int(sd["t"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+        """Takes FlatAdamW's own format, or a torch.optim.AdamW state_dict (what the reference's Lightning checkpoints
+        hold under optimizer_states[0], and what earlier checkpoints of this package held): per-parameter exp_avg /
+        exp_avg_sq / step in the order of model.parameters() over the parameters that had a gradient."""
+        if sd.get("flat_adamw"):
+            if list(sd["names"]) != list(self.names):
+                raise ValueError("FlatAdamW.load_state_dict: checkpoint was written for another parameter list")
+            self.t = int(sd["t"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            for g, s in zip(self.param_groups, sd["param_groups"]):
+                g.update(s)
+            return
+        if "state" not in sd or "param_groups" not in sd:
+            raise ValueError("FlatAdamW.load_state_dict: neither a FlatAdamW nor a torch.optim.AdamW state_dict")
+        self._load_torch_adamw(sd)
+
+    def _load_torch_adamw(self, sd, param_order=None):
+        """param_order: names in the order the torch optimizer was given its parameters (default: model order of the
+        trainable parameters, i.e. self._model_order); torch numbers them 0..n-1 across its param_groups."""
+        order = list(param_order) if param_order is not None else list(self._model_order)
+        ids = [i for g in sd["param_groups"] for i in g["params"]]
+        if len(ids) != len(order):
+            raise ValueError(f"FlatAdamW.load_state_dict: torch state has {len(ids)} parameters, the model {len(order)}")
+        offs, off = {}, 0
+        for n, p in zip(self.names, self._params):
+            offs[n] = (off, p.numel())
+            off += p.numel()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = set()
+        for i, name in zip(ids, order):
+            st = sd["state"].get(i)
+            if st is None:                                   # never received a gradient (Q1 / K2): torch keeps no state
+                continue
+            o, k = offs[name]
+            if st["exp_avg"].numel() != k:
+                raise ValueError(f"FlatAdamW.load_state_dict: {name} has {k} elements, the checkpoint {st['exp_avg'].numel()}")
+            if o >= self.n_active:
+                raise ValueError(f"FlatAdamW.load_state_dict: {name} carries optimizer state but is excluded from the update here")
+            self.exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError(f"FlatAdamW.load_state_dict: parameters at different step counts {sorted(steps)}")
+        self.t = steps.pop() if steps else 0
+        g0 = sd["param_groups"][0]
+        if g0.get("amsgrad") or g0.get("maximize"):
+            raise ValueError("FlatAdamW.load_state_dict: amsgrad / maximize checkpoints are not supported")
+        for k in ("lr", "betas", "eps", "weight_decay", "initial_lr"):
+            if k in g0:
+                self.param_groups[0][k] = tuple(g0[k]) if k == "betas" else g0[k]

@@ -110,3 +110,14 @@ def test_flat_adamw_matches_torch_adamw_with_clipping(golden, name):
     fa2 = FlatAdamW(a.named_parameters(), unused=unused, **hp)
     fa2.load_state_dict(sd)
     assert fa2.t == 6 and torch.equal(fa2.exp_avg, fa.exp_avg)
+    # a torch.optim.AdamW state_dict (reference checkpoints, earlier checkpoints of this package) loads into the flat
+    # buffers: same moments, same step count, and the next step of both optimizers agrees
+    fa3 = FlatAdamW(a.named_parameters(), unused=unused, foreach=None, fused=None, **hp)
+    fa3.load_state_dict(ta.state_dict())
+    assert fa3.t == 6
+    torch.testing.assert_close(fa3.exp_avg.cpu(), fa.exp_avg.cpu(), rtol=2e-5, atol=1e-9)
+    torch.testing.assert_close(fa3.exp_avg_sq.cpu(), fa.exp_avg_sq.cpu(), rtol=2e-5, atol=1e-12)
+    with pytest.raises(ValueError):
+        FlatAdamW(a.named_parameters(), unused=unused, maximize=True, **hp)
+    with pytest.raises(ValueError):
+        fa3.load_state_dict({"something": "else"})

@@ -154,6 +154,10 @@ class MultiModalBridgeMatching(nn.Module):
                 self._fused_cache = (ver, fused_epic.pack_model(self))
         return self._fused_cache[1]
 
+    def fused_training_available(self):
+        """True when training steps of this model run through the fused per-jet kernels (a compiled width set)."""
+        return bool(self.use_fused_training) and self._fused_pack() is not None
+
     @staticmethod
     def _pack_serves(pack, state):
         """multi: hybrid states; uni: discrete-only states"""

@@ -43,7 +43,7 @@ def rel_err(got, ref):
 GRAD_TOL = 1.4e-5          # measured worst 2.83e-6 (S2 output_layer.weight_g, fused path vs the reference)
 GRAD_NORM_TOL = 5.5e-6     # measured worst 1.13e-6 (global gradient norm)
 GRAD_TOL_FULL_SIZE = 3.7e-4   # fused vs layered HIP step at B=1024, N=128, dropout 0.2: measured 7.5e-5
-GRAD_TOL_RERUN = 1.7e-6    # the same fused step twice (atomics order only): measured 3.5e-7
+GRAD_TOL_RERUN = 2.5e-6    # the same fused step twice (atomics order only): measured 3.5e-7 .. 5.0e-7
 
 
 def grads_close(got, ref, golden_name, path, tol=None, what=""):

@@ -286,6 +286,7 @@ def main():
             sys.stderr.flush()
             os._exit(13)
         if rank == 0:
+            tr["roofline"] = training_roofline(model, config, args.workload, B, tr)
             print(json.dumps({
                 "metric": f"training jets/sec @{config.data.max_num_particles} particles", "value": tr["value"],
                 "unit": "jets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -403,6 +403,23 @@ int mmb_attention_fwd(int B, int N, int H, int nheads, const float* qkv, int64_t
 int mmb_attention_bwd(int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld, const float* maskf,
                       int valid_is_zero, const float* out, int64_t out_ld, const float* dout, int64_t dout_ld,
                       const float* lse, float* dqkv, int64_t dqkv_ld, void* stream);
+/* The same two ops with dropout on the attention probabilities, as nn.MultiheadAttention applies it in training mode
+ * (nn.TransformerEncoderLayer(dropout=p), particle_transformer.py:29-35): out = dropout(softmax(.)) @ V.  The keep
+ * decision of (jet b, head h, query q, j-th valid key) is word j & 3 of Philox4x32(seed, offset, index =
+ * ((b*nheads + h)*N + q) * ceil(N/4) + (j >> 2)), kept iff u >= drop_p, kept probabilities scaled by 1/(1 - drop_p);
+ * the reverse pass regenerates the bits from the same (seed, offset).  lse is that of the UNdropped scores.
+ * drop_p = 0 is mmb_attention_fwd / _bwd.  (torch draws its mask from its own generator: same law, other stream.) */
+int mmb_attention_dropout_fwd(int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld, const float* maskf,
+                              int valid_is_zero, float* out, int64_t out_ld, float* lse, float drop_p, uint64_t seed,
+                              uint64_t offset, void* stream);
+int mmb_attention_dropout_bwd(int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld, const float* maskf,
+                              int valid_is_zero, const float* out, int64_t out_ld, const float* dout, int64_t dout_ld,
+                              const float* lse, float* dqkv, int64_t dqkv_ld, float drop_p, uint64_t seed,
+                              uint64_t offset, void* stream);
+/* the keep factors of the call above as a dense tensor out (B, nheads, N, N) [b,h,q,n]: 1/(1-drop_p) or 0 at the valid
+ * keys n, 0 at the others -- for tests that rebuild the dropped attention with another implementation. */
+int mmb_attention_dropout_mask(int B, int N, int nheads, const float* maskf, int valid_is_zero, float drop_p,
+                               uint64_t seed, uint64_t offset, float* out, void* stream);
 /* nn.LayerNorm over the last dim (norm1 / norm2 of the encoder layer; biased variance, eps inside the root):
  * y = (x - mean)/sqrt(var + eps) * gamma + beta; stats (M,2) | NULL receives (mean, 1/sqrt(var+eps)) per row. */
 int mmb_layernorm_fwd(int64_t M, int D, const float* x, int64_t x_ld, const float* gamma, const float* beta, float eps,

@@ -73,7 +73,8 @@ act_bwd_kernel(int64_t M, int Nout, ActBwd a, float* __restrict__ dZ) {
       g += g2 * act_grad(a.post, s);
     }
     if (a.act != MMB_ACT_NONE) {
-      const float ref = a.pre ? a.pre[row * a.pre_ld + col] : a.y1[row * a.y1_ld + col];
+      // (relu followed by a plain dropout, nothing else: y2 = keep * relu(z) has the sign of z wherever g is not 0)
+      const float ref = a.pre ? a.pre[row * a.pre_ld + col] : a.y1 ? a.y1[row * a.y1_ld + col] : a.y2[row * a.y2_ld + col];
       g *= act_grad(a.act, ref);
     }
     dZ[row * a.dz_ld + col] = g;
@@ -634,7 +635,9 @@ extern "C" int mmb_act_bwd(int64_t M, int Nout, const float* gY1, int64_t gY1_ld
   MMB_REQUIRE(act >= 0 && act <= 4 && post >= 0 && post <= 3, "mmb_act_bwd: bad activation");
   if (gY2 && post != MMB_ACT_NONE) MMB_REQUIRE(y1 || y2, "mmb_act_bwd: post activation needs y1 or y2");
   if (act == MMB_ACT_GELU) MMB_REQUIRE(pre, "mmb_act_bwd: GELU needs the pre-activation");
-  if (act == MMB_ACT_LRELU || act == MMB_ACT_RELU) MMB_REQUIRE(pre || y1, "mmb_act_bwd: (leaky-)relu needs pre or y1");
+  const bool relu_from_y2 = act == MMB_ACT_RELU && !pre && !y1 && y2 && !gY1 && !res2 && post == MMB_ACT_NONE;
+  if (act == MMB_ACT_LRELU || act == MMB_ACT_RELU)
+    MMB_REQUIRE(pre || y1 || relu_from_y2, "mmb_act_bwd: (leaky-)relu needs pre or y1 (or, for relu + dropout alone, y2)");
   if (act == MMB_ACT_SELU) MMB_REQUIRE(y1 && !pre, "mmb_act_bwd: SELU takes its derivative from the output y1 (no residual on it)");
   ActBwd a{gY1, gY2, y1, y2, res2, pre, gY1_ld, gY2_ld, y1_ld, y2_ld, res2_ld, pre_ld, dz_ld, act, post, drop_p, seed, offset};
   hipLaunchKernelGGL(act_bwd_kernel, dim3(stream_grid(M * Nout, 256)), dim3(256), 0, as_stream(stream), M, Nout, a, dZ);

@@ -33,12 +33,33 @@ __device__ inline int compact_keys(const float* __restrict__ maskf, int N, int v
   return *nk_sh;
 }
 
+// Dropout on the attention probabilities (torch's MultiheadAttention: dropout(softmax(.)) @ V, active in training;
+// nn.TransformerEncoderLayer(dropout=p) at particle_transformer.py:29-35).  The keep decision of (jet b, head h, query q,
+// j-th VALID key) is word j & 3 of Philox4(seed, offset, index = ((b*nh + h)*N + q) * ceil(N/4) + (j >> 2)): a thread
+// that walks the keys of one query makes one call per four keys; the reverse pass regenerates the same bits.
+struct AttnDrop {
+  float p, inv_keep;
+  uint64_t seed, offset;
+};
+constexpr uint32_t kAttnDropTag = 0xA77Eu;
+
+__device__ __forceinline__ uint32_t attn_keep4(const AttnDrop& d, int64_t bh, int N, int q, int g) {
+  uint32_t r[4];
+  philox4(d.seed, d.offset, (uint64_t)(bh * N + q) * (uint64_t)((N + 3) >> 2) + (uint64_t)g, kAttnDropTag, r);
+  return (u01(r[0]) >= d.p ? 1u : 0u) | (u01(r[1]) >= d.p ? 2u : 0u) | (u01(r[2]) >= d.p ? 4u : 0u) |
+         (u01(r[3]) >= d.p ? 8u : 0u);
+}
+// 1/(1-p) if the j-th valid key of query q is kept, else 0
+__device__ __forceinline__ float attn_keep1(const AttnDrop& d, int64_t bh, int N, int q, int j) {
+  return ((attn_keep4(d, bh, N, q, j >> 2) >> (j & 3)) & 1u) ? d.inv_keep : 0.0f;
+}
+
 // out[q, h*dh + d] = sum_j softmax_j(scale * q.k_j) v_j over the valid keys j;  lse[(b*nh+h)*N + q] = log sum exp
-template <int DHP>
+template <int DHP, bool DROP>
 __global__ void __launch_bounds__(256)
 attn_fwd_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int64_t ld,
                 const float* __restrict__ maskf, int valid_is_zero, float scale, float* __restrict__ out,
-                int64_t out_ld, float* __restrict__ lse) {
+                int64_t out_ld, float* __restrict__ lse, AttnDrop drop) {
   extern __shared__ float sm[];
   const int b = blockIdx.x / nh, h = blockIdx.x - b * nh;
   int* idx = reinterpret_cast<int*>(sm);
@@ -62,6 +83,7 @@ attn_fwd_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int
       acc[d] = 0.0f;
     }
     float m = -INFINITY, l = 0.0f;
+    uint32_t kb = 0;
     for (int j = 0; j < nk; ++j) {
       const float* kr = Ks + j * DHP;
       float s = 0.0f;
@@ -70,10 +92,15 @@ attn_fwd_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int
       const float mn = fmaxf(m, s);
       const float alpha = __expf(m - mn);       // exp(-inf) = 0 on the first key
       const float p = __expf(s - mn);
-      l = fmaf(l, alpha, p);
+      l = fmaf(l, alpha, p);                    // the softmax normaliser is that of the UNdropped probabilities
+      float pk = p;
+      if constexpr (DROP) {
+        if ((j & 3) == 0) kb = attn_keep4(drop, blockIdx.x, N, q, j >> 2);
+        pk = ((kb >> (j & 3)) & 1u) ? p * drop.inv_keep : 0.0f;
+      }
       const float* vr = Vs + j * DHP;
 #pragma unroll
-      for (int d = 0; d < DHP; ++d) acc[d] = fmaf(acc[d], alpha, p * vr[d]);
+      for (int d = 0; d < DHP; ++d) acc[d] = fmaf(acc[d], alpha, pk * vr[d]);
       m = mn;
     }
     const float inv = nk > 0 ? 1.0f / l : 0.0f;
@@ -89,12 +116,14 @@ attn_fwd_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int
 //   dV_j = sum_q P_qj dO_q ; dS_qj = P_qj (dO_q . V_j - D_q) ; dQ_q = scale sum_j dS_qj K_j ; dK_j = scale sum_q dS_qj Q_q
 // Phase A: thread = query (keys from LDS).  Phase B: thread = valid key, queries (Q, dO, lse, D) from the SAME LDS
 // area re-filled.  Keys that are not valid get zero dK, dV.
-template <int DHP>
+// With dropout (keep factor c_qj in {0, 1/(1-p)}): O = sum_j c_qj P_qj V_j, so dV_j = sum_q c_qj P_qj dO_q and
+// dS_qj = P_qj (c_qj dO_q . V_j - D_q) with the same D_q = dO_q . O_q.
+template <int DHP, bool DROP>
 __global__ void __launch_bounds__(256)
 attn_bwd_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int64_t ld,
                 const float* __restrict__ maskf, int valid_is_zero, float scale, const float* __restrict__ out,
                 int64_t out_ld, const float* __restrict__ dout, int64_t dout_ld, const float* __restrict__ lse,
-                float* __restrict__ dqkv, int64_t dld) {
+                float* __restrict__ dqkv, int64_t dld, AttnDrop drop) {
   extern __shared__ float sm[];
   const int b = blockIdx.x / nh, h = blockIdx.x - b * nh;
   int* idx = reinterpret_cast<int*>(sm);
@@ -128,6 +157,7 @@ attn_bwd_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int
       dq[d] = 0.0f;
     }
     const float L = lrow[q];
+    uint32_t kb = 0;
     for (int j = 0; j < nk; ++j) {
       const float* kr = A0 + j * DHP;
       const float* vr = A1 + j * DHP;
@@ -136,6 +166,10 @@ attn_bwd_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int
       for (int d = 0; d < DHP; ++d) {
         s = fmaf(qv[d], kr[d], s);
         dp = fmaf(go[d], vr[d], dp);
+      }
+      if constexpr (DROP) {
+        if ((j & 3) == 0) kb = attn_keep4(drop, blockIdx.x, N, q, j >> 2);
+        dp = ((kb >> (j & 3)) & 1u) ? dp * drop.inv_keep : 0.0f;
       }
       const float ds = __expf(s - L) * (dp - D);
 #pragma unroll
@@ -177,10 +211,16 @@ attn_bwd_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int
           dp = fmaf(gr[d], vv[d], dp);
         }
         const float p = __expf(s - Ls[q]);
+        float pk = p;
+        if constexpr (DROP) {
+          const float c = attn_keep1(drop, blockIdx.x, N, q, j);
+          dp *= c;
+          pk = p * c;
+        }
         const float ds = p * (dp - Ds[q]);
 #pragma unroll
         for (int d = 0; d < DHP; ++d) {
-          dv[d] = fmaf(p, gr[d], dv[d]);
+          dv[d] = fmaf(pk, gr[d], dv[d]);
           dk[d] = fmaf(ds, qr[d], dk[d]);
         }
       }
@@ -360,11 +400,11 @@ __device__ __forceinline__ void jet_head_of_block(int nh, int& b, int& h) {
   }
 }
 
-template <int DH, bool VEC>
+template <int DH, bool VEC, bool DROP>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DH == 16 ? 8 : 6)))
 attn_fwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int64_t ld,
                      const float* __restrict__ maskf, int valid_is_zero, float scale, float* __restrict__ out,
-                     int64_t out_ld, float* __restrict__ lse) {
+                     int64_t out_ld, float* __restrict__ lse, AttnDrop drop) {
   constexpr int P = DH + 4, HD = DH / 2, DT = (DH + 31) / 32;
   extern __shared__ float sm[];
   int b, h;
@@ -420,6 +460,14 @@ attn_fwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv
       ps += __shfl_xor(ps, 32);
       l = fmaf(l, alpha, ps);
       m = mn;
+      if constexpr (DROP) {                      // registers 4g..4g+3 of a lane hold four consecutive keys of its query
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const uint32_t kb = attn_keep4(drop, (int64_t)b * nh + h, N, q < N ? q : 0, (kt + 8 * g + 4 * par) >> 2);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s[4 * g + i] = ((kb >> i) & 1u) ? s[4 * g + i] * drop.inv_keep : 0.0f;
+        }
+      }
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
 #pragma unroll
@@ -436,12 +484,12 @@ attn_fwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv
   }
 }
 
-template <int DH, bool VEC>
+template <int DH, bool VEC, bool DROP>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DH == 16 ? 4 : 3)))
 attn_bwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int64_t ld,
                      const float* __restrict__ maskf, int valid_is_zero, float scale, const float* __restrict__ out,
                      int64_t out_ld, const float* __restrict__ dout, int64_t dout_ld, const float* __restrict__ lse,
-                     float* __restrict__ dqkv, int64_t dld) {
+                     float* __restrict__ dqkv, int64_t dld, AttnDrop drop) {
   constexpr int P = DH + 4, HD = DH / 2, DT = (DH + 31) / 32;
   extern __shared__ float sm[];
   int b, h;
@@ -499,6 +547,14 @@ attn_bwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv
         s = MMB_MFMA_F32(kr[i], qr[i], s);
         dp = MMB_MFMA_F32(vr[i], gr[i], dp);
       }
+      if constexpr (DROP) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const uint32_t kb = attn_keep4(drop, (int64_t)b * nh + h, N, q < N ? q : 0, (kt + 8 * g + 4 * par) >> 2);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dp[4 * g + i] = ((kb >> i) & 1u) ? dp[4 * g + i] * drop.inv_keep : 0.0f;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float p = kt + crow(r, par) < nk ? __builtin_amdgcn_exp2f(s[r] - L) : 0.0f;
@@ -553,8 +609,10 @@ attn_bwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv
         for (int r = 0; r < 16; ++r) {
           const int qq = qt + crow(r, par);
           const float p = qq < N ? __builtin_amdgcn_exp2f(s[r] - Ls[qq]) : 0.0f;
-          dp[r] = p * (dp[r] - Ds[qq]);
-          s[r] = p;
+          float c = 1.0f;
+          if constexpr (DROP) c = attn_keep1(drop, (int64_t)b * nh + h, N, qq < N ? qq : 0, kt + col);   // (lane = key)
+          dp[r] = p * (dp[r] * c - Ds[qq]);
+          s[r] = p * c;
         }
 #pragma unroll
         for (int t = 0; t < DT; ++t)
@@ -801,6 +859,22 @@ sum_replicas_kernel(int64_t n, int R, int64_t stride, const float* __restrict__ 
   }
 }
 
+// the keep factors as a dense (B, nh, N, N) tensor [b,h,q,n]: 1/(1-p) or 0 at the valid keys n, 0 elsewhere (tests)
+__global__ void __launch_bounds__(256)
+attn_dropout_mask_kernel(int64_t total, int N, int nh, const float* __restrict__ maskf, int valid_is_zero, AttnDrop drop,
+                         float* __restrict__ out) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(e % N);
+    const int64_t bh = e / N, b = bh / nh;
+    int j = 0;
+    for (int n = 0; n < N; ++n) {
+      const bool ok = ((maskf[b * N + n] == 0.0f) == (valid_is_zero != 0));
+      out[e * N + n] = ok ? attn_keep1(drop, bh, N, q, j) : 0.0f;
+      j += ok ? 1 : 0;
+    }
+  }
+}
+
 static size_t attn_lds_bytes(int N, int dhp, bool bwd) {
   size_t fl = ((N + 1 + 3) & ~3) + 2 * (size_t)N * dhp;
   if (bwd) fl += N + ((N + 3) & ~3);
@@ -813,14 +887,23 @@ static int pad_dh(int dh) { return dh <= 4 ? 4 : dh <= 8 ? 8 : dh <= 16 ? 16 : d
 
 using namespace mmb;
 
-#define MMB_ATTN_DISPATCH(KERNEL, ...)                                                              \
+#define MMB_ATTN_DISPATCH_D(KERNEL, DROPV, ...)                                                       \
   switch (dhp) {                                                                                    \
-    case 4: hipLaunchKernelGGL((KERNEL<4>), grid, block, lds, st, __VA_ARGS__); break;              \
-    case 8: hipLaunchKernelGGL((KERNEL<8>), grid, block, lds, st, __VA_ARGS__); break;              \
-    case 16: hipLaunchKernelGGL((KERNEL<16>), grid, block, lds, st, __VA_ARGS__); break;            \
-    case 32: hipLaunchKernelGGL((KERNEL<32>), grid, block, lds, st, __VA_ARGS__); break;            \
-    default: hipLaunchKernelGGL((KERNEL<64>), grid, block, lds, st, __VA_ARGS__); break;            \
+    case 4: hipLaunchKernelGGL((KERNEL<4, DROPV>), grid, block, lds, st, __VA_ARGS__); break;       \
+    case 8: hipLaunchKernelGGL((KERNEL<8, DROPV>), grid, block, lds, st, __VA_ARGS__); break;       \
+    case 16: hipLaunchKernelGGL((KERNEL<16, DROPV>), grid, block, lds, st, __VA_ARGS__); break;     \
+    case 32: hipLaunchKernelGGL((KERNEL<32, DROPV>), grid, block, lds, st, __VA_ARGS__); break;     \
+    default: hipLaunchKernelGGL((KERNEL<64, DROPV>), grid, block, lds, st, __VA_ARGS__); break;     \
   }
+#define MMB_ATTN_DISPATCH(KERNEL, ...)                                      \
+  if (drop.p > 0.0f) { MMB_ATTN_DISPATCH_D(KERNEL, true, __VA_ARGS__) }     \
+  else { MMB_ATTN_DISPATCH_D(KERNEL, false, __VA_ARGS__) }
+
+static int attn_drop_args(const char* fn, float p, uint64_t seed, uint64_t offset, AttnDrop& d) {
+  MMB_REQUIRE(p >= 0.0f && p < 1.0f, "%s: dropout probability %g outside [0, 1)", fn, (double)p);
+  d = AttnDrop{p, 1.0f / (1.0f - p), seed, offset};
+  return MMB_OK;
+}
 
 static int attn_check(const char* fn, int B, int N, int H, int nheads, int64_t ld, size_t lds) {
   MMB_REQUIRE(B > 0 && N > 0 && H > 0 && nheads > 0, "%s: empty shape", fn);
@@ -833,43 +916,72 @@ static int attn_check(const char* fn, int B, int N, int H, int nheads, int64_t l
   return MMB_OK;
 }
 
-extern "C" int mmb_attention_fwd(int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld,
-                                 const float* maskf, int valid_is_zero, float* out, int64_t out_ld, float* lse,
-                                 void* stream) {
-  MMB_REQUIRE(qkv && maskf && out, "mmb_attention_fwd: NULL argument");
+static int attention_fwd_impl(const char* fn, int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld,
+                              const float* maskf, int valid_is_zero, float* out, int64_t out_ld, float* lse,
+                              const AttnDrop& drop, void* stream) {
+  MMB_REQUIRE(qkv && maskf && out, "%s: NULL argument", fn);
   const int dh = nheads > 0 ? H / nheads : 0, dhp = pad_dh(dh);
   const bool mfma = N > 0 && dh > 0 && attn_use_mfma(N, dh, false);
   const size_t lds = mfma ? attn_mfma_lds_bytes(N, dh <= 16 ? 16 : 32, false) : attn_lds_bytes(N, dhp, false);
-  if (int rc = attn_check("mmb_attention_fwd", B, N, H, nheads, qkv_ld, lds)) return rc;
-  MMB_REQUIRE(out_ld >= H, "mmb_attention_fwd: out row stride < H");
+  if (int rc = attn_check(fn, B, N, H, nheads, qkv_ld, lds)) return rc;
+  MMB_REQUIRE(out_ld >= H, "%s: out row stride < H", fn);
   dim3 grid(B * nheads), block(N <= 64 ? 64 : N <= 128 ? 128 : N <= 192 ? 192 : 256);
   hipStream_t st = as_stream(stream);
   const float scale = 1.0f / sqrtf((float)dh);
   if (mfma) {
     block = dim3(64 * ((N + 31) / 32));
     const bool vec = dh % 4 == 0 && qkv_ld % 4 == 0 && out_ld % 4 == 0 && aligned16(qkv) && aligned16(out);
-#define MMB_FWD_MFMA(DHV, VECV)                                                                                \
-  hipLaunchKernelGGL((attn_fwd_mfma_kernel<DHV, VECV>), grid, block, lds, st, N, H, nheads, dh, qkv, qkv_ld, maskf, \
-                     valid_is_zero, scale, out, out_ld, lse)
-    if (dh <= 16) { if (vec) MMB_FWD_MFMA(16, true); else MMB_FWD_MFMA(16, false); }
-    else { if (vec) MMB_FWD_MFMA(32, true); else MMB_FWD_MFMA(32, false); }
+#define MMB_FWD_MFMA(DHV, VECV, DROPV)                                                                                \
+  hipLaunchKernelGGL((attn_fwd_mfma_kernel<DHV, VECV, DROPV>), grid, block, lds, st, N, H, nheads, dh, qkv, qkv_ld,    \
+                     maskf, valid_is_zero, scale, out, out_ld, lse, drop)
+#define MMB_FWD_MFMA2(DHV, VECV) do { if (drop.p > 0.0f) MMB_FWD_MFMA(DHV, VECV, true); else MMB_FWD_MFMA(DHV, VECV, false); } while (0)
+    if (dh <= 16) { if (vec) MMB_FWD_MFMA2(16, true); else MMB_FWD_MFMA2(16, false); }
+    else { if (vec) MMB_FWD_MFMA2(32, true); else MMB_FWD_MFMA2(32, false); }
+#undef MMB_FWD_MFMA2
 #undef MMB_FWD_MFMA
-    return check_launch("mmb_attention_fwd");
+    return check_launch(fn);
   }
-  MMB_ATTN_DISPATCH(attn_fwd_kernel, N, H, nheads, dh, qkv, qkv_ld, maskf, valid_is_zero, scale, out, out_ld, lse);
-  return check_launch("mmb_attention_fwd");
+  MMB_ATTN_DISPATCH(attn_fwd_kernel, N, H, nheads, dh, qkv, qkv_ld, maskf, valid_is_zero, scale, out, out_ld, lse, drop);
+  return check_launch(fn);
 }
 
-extern "C" int mmb_attention_bwd(int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld,
-                                 const float* maskf, int valid_is_zero, const float* out, int64_t out_ld,
-                                 const float* dout, int64_t dout_ld, const float* lse, float* dqkv, int64_t dqkv_ld,
+extern "C" int mmb_attention_fwd(int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld,
+                                 const float* maskf, int valid_is_zero, float* out, int64_t out_ld, float* lse,
                                  void* stream) {
-  MMB_REQUIRE(qkv && maskf && out && dout && lse && dqkv, "mmb_attention_bwd: NULL argument");
+  return attention_fwd_impl("mmb_attention_fwd", B, N, H, nheads, qkv, qkv_ld, maskf, valid_is_zero, out, out_ld, lse,
+                            AttnDrop{0.0f, 1.0f, 0, 0}, stream);
+}
+
+extern "C" int mmb_attention_dropout_fwd(int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld,
+                                         const float* maskf, int valid_is_zero, float* out, int64_t out_ld, float* lse,
+                                         float drop_p, uint64_t seed, uint64_t offset, void* stream) {
+  AttnDrop d;
+  if (int rc = attn_drop_args("mmb_attention_dropout_fwd", drop_p, seed, offset, d)) return rc;
+  return attention_fwd_impl("mmb_attention_dropout_fwd", B, N, H, nheads, qkv, qkv_ld, maskf, valid_is_zero, out, out_ld,
+                            lse, d, stream);
+}
+
+extern "C" int mmb_attention_dropout_mask(int B, int N, int nheads, const float* maskf, int valid_is_zero, float drop_p,
+                                          uint64_t seed, uint64_t offset, float* out, void* stream) {
+  MMB_REQUIRE(B > 0 && N > 0 && nheads > 0 && maskf && out, "mmb_attention_dropout_mask: bad argument");
+  AttnDrop d;
+  if (int rc = attn_drop_args("mmb_attention_dropout_mask", drop_p, seed, offset, d)) return rc;
+  const int64_t total = (int64_t)B * nheads * N;
+  hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), total, N,
+                     nheads, maskf, valid_is_zero, d, out);
+  return check_launch("mmb_attention_dropout_mask");
+}
+
+static int attention_bwd_impl(const char* fn, int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld,
+                              const float* maskf, int valid_is_zero, const float* out, int64_t out_ld,
+                              const float* dout, int64_t dout_ld, const float* lse, float* dqkv, int64_t dqkv_ld,
+                              const AttnDrop& drop, void* stream) {
+  MMB_REQUIRE(qkv && maskf && out && dout && lse && dqkv, "%s: NULL argument", fn);
   const int dh = nheads > 0 ? H / nheads : 0, dhp = pad_dh(dh);
   const bool mfma = N > 0 && dh > 0 && attn_use_mfma(N, dh, true);
   const size_t lds = mfma ? attn_mfma_lds_bytes(N, dh <= 16 ? 16 : 32, true) : attn_lds_bytes(N, dhp, true);
-  if (int rc = attn_check("mmb_attention_bwd", B, N, H, nheads, qkv_ld, lds)) return rc;
-  MMB_REQUIRE(out_ld >= H && dout_ld >= H && dqkv_ld >= 3 * (int64_t)H, "mmb_attention_bwd: row stride too small");
+  if (int rc = attn_check(fn, B, N, H, nheads, qkv_ld, lds)) return rc;
+  MMB_REQUIRE(out_ld >= H && dout_ld >= H && dqkv_ld >= 3 * (int64_t)H, "%s: row stride too small", fn);
   dim3 grid(B * nheads), block(N <= 64 ? 64 : N <= 128 ? 128 : N <= 192 ? 192 : 256);
   hipStream_t st = as_stream(stream);
   const float scale = 1.0f / sqrtf((float)dh);
@@ -877,17 +989,37 @@ extern "C" int mmb_attention_bwd(int B, int N, int H, int nheads, const float* q
     block = dim3(64 * ((N + 31) / 32));
     const bool vec = dh % 4 == 0 && qkv_ld % 4 == 0 && out_ld % 4 == 0 && dout_ld % 4 == 0 && dqkv_ld % 4 == 0 &&
                      aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv);
-#define MMB_BWD_MFMA(DHV, VECV)                                                                                \
-  hipLaunchKernelGGL((attn_bwd_mfma_kernel<DHV, VECV>), grid, block, lds, st, N, H, nheads, dh, qkv, qkv_ld, maskf, \
-                     valid_is_zero, scale, out, out_ld, dout, dout_ld, lse, dqkv, dqkv_ld)
-    if (dh <= 16) { if (vec) MMB_BWD_MFMA(16, true); else MMB_BWD_MFMA(16, false); }
-    else { if (vec) MMB_BWD_MFMA(32, true); else MMB_BWD_MFMA(32, false); }
+#define MMB_BWD_MFMA(DHV, VECV, DROPV)                                                                                \
+  hipLaunchKernelGGL((attn_bwd_mfma_kernel<DHV, VECV, DROPV>), grid, block, lds, st, N, H, nheads, dh, qkv, qkv_ld,    \
+                     maskf, valid_is_zero, scale, out, out_ld, dout, dout_ld, lse, dqkv, dqkv_ld, drop)
+#define MMB_BWD_MFMA2(DHV, VECV) do { if (drop.p > 0.0f) MMB_BWD_MFMA(DHV, VECV, true); else MMB_BWD_MFMA(DHV, VECV, false); } while (0)
+    if (dh <= 16) { if (vec) MMB_BWD_MFMA2(16, true); else MMB_BWD_MFMA2(16, false); }
+    else { if (vec) MMB_BWD_MFMA2(32, true); else MMB_BWD_MFMA2(32, false); }
+#undef MMB_BWD_MFMA2
 #undef MMB_BWD_MFMA
-    return check_launch("mmb_attention_bwd");
+    return check_launch(fn);
   }
   MMB_ATTN_DISPATCH(attn_bwd_kernel, N, H, nheads, dh, qkv, qkv_ld, maskf, valid_is_zero, scale, out, out_ld, dout,
-                    dout_ld, lse, dqkv, dqkv_ld);
-  return check_launch("mmb_attention_bwd");
+                    dout_ld, lse, dqkv, dqkv_ld, drop);
+  return check_launch(fn);
+}
+
+extern "C" int mmb_attention_bwd(int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld,
+                                 const float* maskf, int valid_is_zero, const float* out, int64_t out_ld,
+                                 const float* dout, int64_t dout_ld, const float* lse, float* dqkv, int64_t dqkv_ld,
+                                 void* stream) {
+  return attention_bwd_impl("mmb_attention_bwd", B, N, H, nheads, qkv, qkv_ld, maskf, valid_is_zero, out, out_ld, dout,
+                            dout_ld, lse, dqkv, dqkv_ld, AttnDrop{0.0f, 1.0f, 0, 0}, stream);
+}
+
+extern "C" int mmb_attention_dropout_bwd(int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld,
+                                         const float* maskf, int valid_is_zero, const float* out, int64_t out_ld,
+                                         const float* dout, int64_t dout_ld, const float* lse, float* dqkv,
+                                         int64_t dqkv_ld, float drop_p, uint64_t seed, uint64_t offset, void* stream) {
+  AttnDrop d;
+  if (int rc = attn_drop_args("mmb_attention_dropout_bwd", drop_p, seed, offset, d)) return rc;
+  return attention_bwd_impl("mmb_attention_dropout_bwd", B, N, H, nheads, qkv, qkv_ld, maskf, valid_is_zero, out, out_ld,
+                            dout, dout_ld, lse, dqkv, dqkv_ld, d, stream);
 }
 
 extern "C" int mmb_layernorm_fwd(int64_t M, int D, const float* x, int64_t x_ld, const float* gamma, const float* beta,

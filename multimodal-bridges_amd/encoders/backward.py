@@ -322,11 +322,12 @@ def _linear_bwd(e, store, produced, mi, seed, arena, touched):
         koff += Ks
 
 
-def _attn_bwd(e, store, mi):
-    _, qkv, a, lse, nheads = e
+def _attn_bwd(e, store, mi, seed=0):
+    _, qkv, a, lse, nheads = e[:5]
+    p, off = (e[5], e[6]) if len(e) > 5 else (0.0, 0)
     g = store.get(a)
     if g is not None:
-        store.add(qkv, ops.attention_bwd(qkv, mi, nheads, a, g, lse, valid_is_zero=True))
+        store.add(qkv, ops.attention_bwd(qkv, mi, nheads, a, g, lse, valid_is_zero=True, drop_p=p, seed=seed, offset=off))
 
 
 def _ln_bwd(e, store, produced, arena):
@@ -413,7 +414,7 @@ def run_backward(model, tape, heads, d_hc, d_hd, d_s=None, scale=None):
         if kind in ("linear", "plinear"):
             _linear_bwd(e, store, produced, mi, seed, arena, touched)
         elif kind == "attn":
-            _attn_bwd(e, store, mi)
+            _attn_bwd(e, store, mi, seed)
         elif kind == "ln":
             _ln_bwd(e, store, produced, arena)
         elif kind == "pool":

@@ -584,8 +584,9 @@ def grad_weight_smallk(X, dZ, dW, db=None):
 
 
 # ------------------------------------------------------------------------ transformer set encoder
-def attention_fwd(qkv, mi, nheads, valid_is_zero=True, want_lse=False):
-    """qkv (B*N, 3H) [q|k|v] -> out (B*N, H) (+ lse (B, nheads, N) for the backward)."""
+def attention_fwd(qkv, mi, nheads, valid_is_zero=True, want_lse=False, drop_p=0.0, seed=0, offset=0):
+    """qkv (B*N, 3H) [q|k|v] -> out (B*N, H) (+ lse (B, nheads, N) for the backward).  drop_p > 0: dropout on the
+    attention probabilities (training mode of nn.MultiheadAttention), Philox keyed by (seed, offset)."""
     B, N = mi.B, mi.N
     H = qkv.shape[1] // 3
     if qkv.dim() != 2 or qkv.shape[0] != B * N or qkv.shape[1] != 3 * H or qkv.stride(1) != 1:
@@ -593,20 +594,39 @@ def attention_fwd(qkv, mi, nheads, valid_is_zero=True, want_lse=False):
     f32(qkv.new_empty(0), "qkv")                              # device / dtype check
     out = torch.empty(B * N, H, dtype=torch.float32, device=qkv.device)
     lse = torch.empty(B, nheads, N, dtype=torch.float32, device=qkv.device) if want_lse else None
-    call("mmb_attention_fwd", B, N, H, nheads, qkv.data_ptr(), qkv.stride(0), f32(mi.maskf), int(bool(valid_is_zero)),
-         f32(out), out.stride(0), f32(lse), stream())
+    if drop_p > 0.0:
+        call("mmb_attention_dropout_fwd", B, N, H, nheads, qkv.data_ptr(), qkv.stride(0), f32(mi.maskf),
+             int(bool(valid_is_zero)), f32(out), out.stride(0), f32(lse), _fl(drop_p), seed, offset, stream())
+    else:
+        call("mmb_attention_fwd", B, N, H, nheads, qkv.data_ptr(), qkv.stride(0), f32(mi.maskf),
+             int(bool(valid_is_zero)), f32(out), out.stride(0), f32(lse), stream())
     return (out, lse) if want_lse else out
 
 
-def attention_bwd(qkv, mi, nheads, out, dout, lse, valid_is_zero=True):
+def attention_bwd(qkv, mi, nheads, out, dout, lse, valid_is_zero=True, drop_p=0.0, seed=0, offset=0):
     B, N = mi.B, mi.N
     H = qkv.shape[1] // 3
     if dout.stride(1) != 1 or out.stride(1) != 1:
         raise MMBError("attention_bwd: unit inner stride required")
     dqkv = torch.empty(B * N, 3 * H, dtype=torch.float32, device=qkv.device)
-    call("mmb_attention_bwd", B, N, H, nheads, qkv.data_ptr(), qkv.stride(0), f32(mi.maskf), int(bool(valid_is_zero)),
-         out.data_ptr(), out.stride(0), dout.data_ptr(), dout.stride(0), f32(lse), f32(dqkv), dqkv.stride(0), stream())
+    if drop_p > 0.0:
+        call("mmb_attention_dropout_bwd", B, N, H, nheads, qkv.data_ptr(), qkv.stride(0), f32(mi.maskf),
+             int(bool(valid_is_zero)), out.data_ptr(), out.stride(0), dout.data_ptr(), dout.stride(0), f32(lse), f32(dqkv),
+             dqkv.stride(0), _fl(drop_p), seed, offset, stream())
+    else:
+        call("mmb_attention_bwd", B, N, H, nheads, qkv.data_ptr(), qkv.stride(0), f32(mi.maskf),
+             int(bool(valid_is_zero)), out.data_ptr(), out.stride(0), dout.data_ptr(), dout.stride(0), f32(lse), f32(dqkv),
+             dqkv.stride(0), stream())
     return dqkv
+
+
+def attention_dropout_mask(mi, nheads, drop_p, seed, offset, valid_is_zero=True):
+    """(B, nheads, N, N) keep factors [b,h,q,n] of attention_fwd(..., drop_p, seed, offset): 1/(1-p) or 0."""
+    B, N = mi.B, mi.N
+    out = torch.empty(B, nheads, N, N, dtype=torch.float32, device=mi.maskf.device)
+    call("mmb_attention_dropout_mask", B, N, nheads, f32(mi.maskf), int(bool(valid_is_zero)), _fl(drop_p), seed, offset,
+         f32(out), stream())
+    return out
 
 
 def layernorm_fwd(x, gamma, beta, eps=1e-5, want_stats=False, out=None):

@@ -15,8 +15,9 @@ def close(a, b, rtol=1e-4, atol=1e-5):
     torch.testing.assert_close(a.detach().cpu().float(), b.detach().cpu().float(), rtol=rtol, atol=atol)
 
 
-def ref_attention(qkv, mask, nheads, valid_is_zero):
-    """qkv (B,N,3H) float64 -> (B,N,H); keys restricted to mask == 0 (or != 0); no valid key -> zeros."""
+def ref_attention(qkv, mask, nheads, valid_is_zero, keep=None):
+    """qkv (B,N,3H) float64 -> (B,N,H); keys restricted to mask == 0 (or != 0); no valid key -> zeros.
+    keep (B,nheads,N,N) | None: dropout factors on the attention probabilities."""
     B, N, H3 = qkv.shape
     H = H3 // 3
     dh = H // nheads
@@ -29,6 +30,8 @@ def ref_attention(qkv, mask, nheads, valid_is_zero):
     e = torch.exp(s - m)
     den = e.sum(-1, keepdim=True)
     a = torch.where(den > 0, e / den.clamp(min=1e-300), torch.zeros_like(e))
+    if keep is not None:
+        a = a * keep
     return (a @ v).transpose(1, 2).reshape(B, N, H)
 
 
@@ -140,20 +143,175 @@ def test_reference_style_block_call(golden):
     close(h, t["cap:continuous_encoder"], rtol=1e-4, atol=2e-5)
 
 
-def test_transformer_refuses_dropout_in_training(golden):
+@pytest.mark.parametrize("B,N,H,nh", [(5, 16, 8, 2), (3, 11, 12, 2), (4, 150, 64, 4), (3, 150, 128, 4), (2, 70, 128, 2)])
+@pytest.mark.parametrize("path", ["mfma", "valu"])
+def test_attention_dropout_forward_backward(B, N, H, nh, path, monkeypatch):
+    """Dropout on the attention probabilities (training mode of nn.MultiheadAttention inside
+    nn.TransformerEncoderLayer(dropout=p), particle_transformer.py:29-35): the Philox keep factors are extracted
+    (mmb_attention_dropout_mask) and the dropped attention rebuilt in float64 with autograd -- forward, log-sum-exp
+    and all three input gradients; the factors are 0 or 1/(1-p), kept at the rate 1-p, and change with the offset."""
+    from mmb_hip import ops
+    monkeypatch.setenv("MMB_ATTN_PATH", path)
+    p, seed, off = 0.3, 1234567, 5
+    g = torch.Generator().manual_seed(B * 1000 + N + H + 1)
+    qkv = torch.randn(B, N, 3 * H, generator=g)
+    mask = make_mask(B, N, g)
+    dout = torch.randn(B, N, H, generator=g)
+    mi = ops.mask_prepare(mask.cuda())
+    qd = qkv.reshape(B * N, 3 * H).cuda()
+    keep = ops.attention_dropout_mask(mi, nh, p, seed, off).cpu()
+    valid = (mask == 0)[:, None, None, :].expand(B, nh, N, N)
+    assert float(keep[~valid].abs().max() if (~valid).any() else 0.0) == 0.0
+    kv = keep[valid]
+    assert bool(((kv == 0) | ((kv - 1.0 / (1.0 - p)).abs() < 1e-6)).all())
+    n = kv.numel()
+    if n > 2000:
+        rate = float((kv != 0).float().mean())
+        assert abs(rate - (1.0 - p)) < 4.0 * math.sqrt(p * (1.0 - p) / n) + 1e-3, rate
+    other = ops.attention_dropout_mask(mi, nh, p, seed, off + 1).cpu()
+    if n > 200:
+        assert not torch.equal(other, keep)
+    q64 = qkv.double().requires_grad_(True)
+    want = ref_attention(q64, mask, nh, True, keep=keep.double())
+    (want * dout.double()).sum().backward()
+    out, lse = ops.attention_fwd(qd, mi, nh, valid_is_zero=True, want_lse=True, drop_p=p, seed=seed, offset=off)
+    out0, lse0 = ops.attention_fwd(qd, mi, nh, valid_is_zero=True, want_lse=True)
+    scale = float(want.detach().abs().max())
+    close(out.view(B, N, H), want, rtol=1e-4, atol=2e-5 * scale)
+    assert torch.equal(lse, lse0)                              # the normaliser is that of the undropped scores
+    out_again = ops.attention_fwd(qd, mi, nh, valid_is_zero=True, drop_p=p, seed=seed, offset=off)
+    assert torch.equal(out_again, out)
+    dq = ops.attention_bwd(qd, mi, nh, out, dout.reshape(B * N, H).cuda(), lse, valid_is_zero=True, drop_p=p, seed=seed,
+                           offset=off)
+    gs = float(q64.grad.abs().max())
+    close(dq.view(B, N, 3 * H), q64.grad, rtol=1e-4, atol=2e-5 * gs)
+
+
+def _dropout_factors(M, Nout, p, seed, off):
+    """keep factors of the second-stage dropout of mmb_linear_cat for an (M, Nout) output: run it on a layer whose
+    output is 1 everywhere"""
+    from mmb_hip import ops
+    x = torch.zeros(M, 4, device="cuda")
+    W = torch.zeros(Nout, 4, device="cuda")
+    b = torch.ones(Nout, device="cuda")
+    _, y2 = ops.linear_cat([(x, ops.SEG_ROW)], W, b, 1, want_y1=False, out2=torch.empty(M, Nout, device="cuda"),
+                           drop_p=p, seed=seed, offset=off)
+    return y2
+
+
+@pytest.mark.parametrize("name", ["tr_tiny", "tr_odd"])
+def test_transformer_block_with_dropout_matches_float64_with_extracted_masks(golden, name):
+    """One TransformerEncoderBlock in training mode with dropout 0.25: the four Philox masks of every layer (attention
+    probabilities, dropout1 after out_proj, the FFN's inner dropout, dropout2 after linear2) are extracted and
+    nn.TransformerEncoderLayer's arithmetic restated in float64 with them."""
+    import copy
+    from pipeline.configs import ExperimentConfigs
+    from model.multimodal_bridge_matching import MultiModalBridgeMatching
+    from encoders.epic import ExecCtx
+    from mmb_hip import ops
+    F = torch.nn.functional
+    g = golden(name)
+    cfg = copy.deepcopy(g.cfg)
+    cfg["data"]["target_path"] = GOLDEN
+    model = MultiModalBridgeMatching(ExperimentConfigs(cfg))
+    model.load_state_dict(g.params, strict=True)
+    model = model.cuda().train()
+    blk = model.encoder.continuous_encoder
+    t = g.t
+    mask = t["mask"]
+    B, N = mask.shape[:2]
+    p, seed = 0.25, 4242
+    mi = ops.mask_prepare(mask.cuda())
+    ctx = ExecCtx(mi, tape=None, drop_p=p, seed=seed, offset0=0)
+    temb = t["cap:emb.time"].cuda().float().contiguous()                   # (B,N,Et), already masked
+    x = t["cap:emb.continuous"].cuda().float().reshape(B * N, -1).contiguous()
+    got = blk.run(ctx, temb, [(x, ops.SEG_ROW)]).view(B, N, -1)
+    # float64 restatement
+    d = lambda a: a.detach().double().cpu()
+    h = F.linear(d(x), d(blk.input_proj.weight), d(blk.input_proj.bias))
+    tp = blk.time_proj
+    te = d(temb).reshape(B * N, -1)
+    h = h + (F.linear(te, d(tp.weight), d(tp.bias)) if isinstance(tp, torch.nn.Linear) else te)
+    D = h.shape[1]
+    for i, l in enumerate(blk.transformer.layers):
+        o = 4 * i
+        qkv = F.linear(h, d(l.self_attn.in_proj_weight), d(l.self_attn.in_proj_bias))
+        keep = ops.attention_dropout_mask(mi, blk.n_heads, p, seed, o + 1).double().cpu()
+        a = ref_attention(qkv.view(B, N, -1), mask.squeeze(-1), blk.n_heads, True, keep=keep).reshape(B * N, D)
+        m1 = _dropout_factors(B * N, D, p, seed, o + 2).double().cpu()
+        h = F.layer_norm(h + F.linear(a, d(l.self_attn.out_proj.weight), d(l.self_attn.out_proj.bias)) * m1, (D,),
+                         d(l.norm1.weight), d(l.norm1.bias), l.norm1.eps)
+        ff = l.linear1.out_features
+        m2 = _dropout_factors(B * N, ff, p, seed, o + 3).double().cpu()
+        f = F.linear(h, d(l.linear1.weight), d(l.linear1.bias)).relu() * m2
+        m3 = _dropout_factors(B * N, D, p, seed, o + 4).double().cpu()
+        h = F.layer_norm(h + F.linear(f, d(l.linear2.weight), d(l.linear2.bias)) * m3, (D,), d(l.norm2.weight),
+                         d(l.norm2.bias), l.norm2.eps)
+        for m in (m1, m2, m3):
+            assert bool(((m == 0) | ((m - 1.0 / (1.0 - p)).abs() < 1e-6)).all())
+    close(got, h.view(B, N, D), rtol=1e-4, atol=2e-5)
+    # eval mode: no dropout, the golden capture
+    model.eval()
+    h_eval = blk(t["cap:emb.time"].cuda(), t["cap:emb.continuous"].cuda(), t["mask"].cuda())
+    close(h_eval, t["cap:continuous_encoder"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["tr_tiny", "S4"])
+def test_transformer_training_step_with_dropout(golden, name):
+    """The reference's S4 block trains with dropout 0.2.  Training steps with dropout: deterministic for a seed,
+    different for another, and the reverse pass (which regenerates every mask) agrees with central finite differences
+    of the loss along the gradient direction, the masks being the same at both points."""
     import copy
     from pipeline.configs import ExperimentConfigs
     from model.multimodal_bridge_matching import MultiModalBridgeMatching
     from tensorclass import TensorMultiModal
-    g = golden("tr_tiny")
+    from datamodules.datasets import DataCoupling
+    g = golden(name)
     cfg = copy.deepcopy(g.cfg)
     cfg["data"]["target_path"] = GOLDEN
-    cfg["encoder"]["dropout"] = 0.1
-    model = MultiModalBridgeMatching(ExperimentConfigs(cfg)).cuda().train()
+    cfg["encoder"]["dropout"] = 0.2
+    model = MultiModalBridgeMatching(ExperimentConfigs(cfg))
+    model.load_state_dict(g.params, strict=True)
+    model = model.cuda().train()
     t = g.t
-    state = TensorMultiModal(t["time"].cuda(), t["xt"].cuda(), t["kt"].cuda(), t["mask"].cuda())
-    with pytest.raises(NotImplementedError):
-        model(state, None)
+    c = lambda a: None if a is None else a.cuda()
+
+    def loss_and_grads(seed, want_grads=True):
+        model.manual_seed(seed)
+        state = TensorMultiModal(c(t["time"]), c(t.get("xt")), c(t["kt"]), c(t["mask"]))
+        src = TensorMultiModal(None, c(t.get("x0")), c(t["k0"]), torch.ones_like(c(t["mask"])))
+        batch = DataCoupling(src, TensorMultiModal(None, c(t.get("x1")), c(t["k1"]), c(t["mask"])), None)
+        out = model.step_from_state(state, batch, "train", True)
+        if not want_grads:
+            return out["loss"].detach().double().item(), None
+        model.zero_grad(set_to_none=True)
+        out["loss"].backward()
+        return out["loss"].detach().double().item(), {n: q.grad.detach().clone() for n, q in model.named_parameters()
+                                                      if q.grad is not None}
+
+    l1, g1 = loss_and_grads(5)
+    l1b, g1b = loss_and_grads(5)
+    l2, _ = loss_and_grads(6, want_grads=False)
+    assert l1 == l1b and l1 != l2
+    assert abs(l1 - float(t["loss"])) > 1e-6 * abs(l1)         # not the dropout-free golden loss
+    for n in g1:
+        close(g1b[n], g1[n], rtol=1e-4, atol=1e-5 * float(g1[n].abs().max()) + 1e-9)
+    # directional derivative along the gradient (encoder parameters only: where the dropout sits)
+    names = [n for n in g1 if ".transformer.layers." in n or "input_proj" in n]
+    gn = math.sqrt(sum(float((g1[n].double() ** 2).sum()) for n in names))
+    params = dict(model.named_parameters())
+    eps = 2e-3 / gn * max(abs(l1), 1.0) if name == "tr_tiny" else 5e-4 / gn * max(abs(l1), 1.0)
+    def shifted(sign):
+        with torch.no_grad():
+            for n in names:
+                params[n].add_(g1[n], alpha=sign * eps / gn)
+        val, _ = loss_and_grads(5, want_grads=False)
+        with torch.no_grad():
+            for n in names:
+                params[n].sub_(g1[n], alpha=sign * eps / gn)
+        return val
+    fd = (shifted(+1.0) - shifted(-1.0)) / (2.0 * eps)
+    assert abs(fd - gn) <= 0.03 * gn, (fd, gn)
 
 
 @pytest.mark.parametrize("M,K,Nout", [(6000, 64, 64), (6000, 256, 64), (4100, 128, 128), (6000, 256, 128),

@@ -16,5 +16,6 @@ for wl in S3 S2; do
 done
 timeout -s KILL 240 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $out/sq_S3 -o p -- python3 $root/bench.py --no-cpu-baseline --no-train --steps 1 --warmup 1 > $out/pmc_sq_S3.json 2> $out/pmc_sq_S3.err || { echo "sq pass failed"; tail -5 $out/pmc_sq_S3.err; exit 1; }
 timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_IFETCH SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --output-format csv -d $out/sq2_S3 -o p -- python3 $root/bench.py --no-cpu-baseline --no-train --steps 1 --warmup 1 > $out/pmc_sq2_S3.json 2> $out/pmc_sq2_S3.err || { echo "sq2 pass failed"; tail -5 $out/pmc_sq2_S3.err; }
+timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM --output-format csv -d $out/sq3_S3 -o p -- python3 $root/bench.py --no-cpu-baseline --no-train --steps 1 --warmup 1 > $out/pmc_sq3_S3.json 2> $out/pmc_sq3_S3.err || { echo "sq3 pass failed"; tail -5 $out/pmc_sq3_S3.err; }
 timeout -s KILL 240 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE --output-format csv -d $out/ic_S3 -o p -- python3 $root/bench.py --no-cpu-baseline --no-train --steps 1 --warmup 1 > $out/pmc_ic_S3.json 2> $out/pmc_ic_S3.err || { echo "icache pass failed"; tail -5 $out/pmc_ic_S3.err; }
 find $out -name "*.csv" | head -40

@@ -63,9 +63,16 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&x)[HT]) {
 template <int KT, int OT, typename TileFn>
 __device__ __forceinline__ void mma_go(f32x16 (&acc)[OT], TileFn&& tile, const float* P, int woff, int lane) {
   const WRsrc R = weight_rsrc(P);
+#ifdef MMB_BWD_MMA_X              // the round-2 stream (two fragments ahead, issue order left to the compiler)
   AFrag<OT> pre;
   mma_prefetch(pre, R, woff, lane);
   mma_x<KT, OT>(acc, tile, R, woff, lane, pre);
+#else                             // the forward's pinned software pipeline (fused_common.h: mma_r), one ring per GEMM
+  constexpr int RD = (KT * 2 * OT) % 4 == 0 ? 4 : 2;
+  WRing<RD> ring;
+  ring_prime(ring, R, woff, lane * 16);
+  mma_r<KT, OT, RD, false>(acc, tile, R, woff, 0, lane * 16, ring);
+#endif
 }
 
 // s = column sums of the dZ tiles over the jet's particles -> LB.svec and row b of the next slot

@@ -392,6 +392,19 @@ def main():
                             "configured batch is latency-bound; --batch 32768 fills the chip",
                     "launches": tz["n"], "avg_launch_us": tz["ms"] * 1e3 / tz["n"],
                     "share_of_gpu_time": tz["ms"] / total_ms}
+        elif groups.get("mmb_transformer_tail") and groups["mmb_transformer_tail"]["ms"] >= max(g["ms"] for g in groups.values()):
+            tl = groups["mmb_transformer_tail"]
+            achieved = tl["flops"] / (tl["ms"] * 1e-3) / 1e12
+            roof = {"kernel": "transformer_tail_kernel (out_proj + LayerNorm1 + FFN + LayerNorm2 + next in_proj per launch; "
+                              "fp32 products as 6 x v_mfma_f32_32x32x16_bf16 over a 3-plane exact operand split)",
+                    "bound": "mfma", "achieved": 6 * achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": 6 * achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
+                    "algorithmic_fp32_tflops": achieved,
+                    "algorithmic_frac_of_native_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+                    "launches": tl["n"], "avg_launch_us": tl["ms"] * 1e3 / tl["n"],
+                    "share_of_gpu_time": tl["ms"] / total_ms,
+                    "note": "the S4 generation pass is three kernels of similar weight: this one, mmb_attention_fwd "
+                            "and the remaining mmb_linear_cat launches (kernel_time_ms)"}
         elif dom:
             achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             # the group holds every per-particle mmb_linear_cat launch: most run linear_stream_x6_kernel (fp32 products

@@ -420,6 +420,20 @@ int mmb_attention_dropout_bwd(int B, int N, int H, int nheads, const float* qkv,
  * keys n, 0 at the others -- for tests that rebuild the dropped attention with another implementation. */
 int mmb_attention_dropout_mask(int B, int N, int nheads, const float* maskf, int valid_is_zero, float drop_p,
                                uint64_t seed, uint64_t offset, float* out, void* stream);
+/* The per-particle tail of one encoder layer in one launch, inference arithmetic (no dropout):
+ *   h1 = LayerNorm1(h + out_proj(a));  out = LayerNorm2(h1 + linear2(relu(linear1(h1))));  qkv = in_proj_next(out)
+ * (nn.TransformerEncoderLayer.forward as built at particle_transformer.py:29-35, post-LN, ReLU), replacing two
+ * mmb_linear_cat_ln and two mmb_linear_cat launches: h1 and the FFN's hidden tensor never reach HBM.  a (M,d): attention
+ * output; h (M,d): the layer's input (residual); out (M,d); qkv (M,3d) | NULL: the next layer's in_proj applied to out.
+ * d = 64 or 128, ff a multiple of 64 (<= 1024).  packed = n_vec = 9d + ff floats [b_o | gamma1 | beta1 | b2 | gamma2 |
+ * beta2 | b1 | b_in] followed by the weights in MFMA fragment order, three bf16 planes per fp32 value (INTEGRATION.md,
+ * "Parameter block"; mmb_hip/fused.py: pack_transformer_tail): W_o, then per 64-unit FFN chunk c W1[64c:64c+64, :] (block
+ * wx_1) and W2[:, 64c:64c+64] (block wx_2), then the three d x d blocks of in_proj; wx_*: float offsets from the start of
+ * the fragment part.  All row strides multiples of 4 floats, all pointers 16-byte aligned.  Results are fp32 results
+ * (exact three-plane split, six partial products). */
+int mmb_transformer_tail(int64_t M, int d, int ff, const float* packed, int n_vec, int wx_o, int wx_1, int wx_2, int wx_in,
+                         const float* a, int64_t a_ld, const float* h, int64_t h_ld, float* out, int64_t out_ld, float* qkv,
+                         int64_t qkv_ld, float eps1, float eps2, void* stream);
 /* nn.LayerNorm over the last dim (norm1 / norm2 of the encoder layer; biased variance, eps inside the root):
  * y = (x - mean)/sqrt(var + eps) * gamma + beta; stats (M,2) | NULL receives (mean, 1/sqrt(var+eps)) per row. */
 int mmb_layernorm_fwd(int64_t M, int D, const float* x, int64_t x_ld, const float* gamma, const float* beta, float eps,

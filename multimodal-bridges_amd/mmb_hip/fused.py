@@ -18,6 +18,7 @@ import os
 import torch
 
 from . import call
+import mmb_hip as _m
 from .ops import f32, i32, i64, stream, _fl
 
 VARIANTS = {  # (Et, Ec, Ed, Hb, Gb) -> variant id (csrc/fused_common.h: DimsS3 / DimsMid / DimsWide / DimsNarrow)
@@ -351,6 +352,58 @@ def split_planes(xs):
     mid = r.bfloat16()
     lo = (r - mid.float()).bfloat16()
     return torch.stack([hi, mid, lo], dim=1).contiguous().view(torch.float32).reshape(-1)
+
+
+def pack_transformer_tail(layer, next_layer=None):
+    """Parameter block of mmb_transformer_tail for one nn.TransformerEncoderLayer (+ the in_proj of the layer after it):
+    -> dict(packed, n_vec, wx_o, wx_1, wx_2, wx_in, d, ff, eps1, eps2, has_in)."""
+    sa = layer.self_attn
+    Wo, W1, W2 = sa.out_proj.weight.detach().float(), layer.linear1.weight.detach().float(), layer.linear2.weight.detach().float()
+    d, ff = Wo.shape[0], W1.shape[0]
+    dev = Wo.device
+    if next_layer is not None:
+        Win, b_in = next_layer.self_attn.in_proj_weight.detach().float(), next_layer.self_attn.in_proj_bias.detach().float()
+    else:
+        Win, b_in = None, torch.zeros(3 * d, device=dev)
+    vec = torch.cat([sa.out_proj.bias.detach().float(), layer.norm1.weight.detach().float(), layer.norm1.bias.detach().float(),
+                     layer.linear2.bias.detach().float(), layer.norm2.weight.detach().float(), layer.norm2.bias.detach().float(),
+                     layer.linear1.bias.detach().float(), b_in])
+    blocks, offs, n = [], {}, 0
+
+    def add(name, W):
+        nonlocal n
+        u = _Packer.pack_x(W)
+        offs.setdefault(name, n * FRAG_FLOATS)
+        blocks.append(u)
+        n += u.shape[0]
+
+    add("wx_o", Wo)
+    for c in range(ff // 64):
+        add("wx_1", W1[64 * c:64 * c + 64, :])
+    for c in range(ff // 64):
+        add("wx_2", W2[:, 64 * c:64 * c + 64])
+    if Win is not None:
+        for j in range(3):
+            add("wx_in", Win[d * j:d * (j + 1), :])
+    packed = torch.cat([vec, split_planes(torch.cat(blocks))]).contiguous()
+    return dict(packed=packed, n_vec=vec.numel(), d=d, ff=ff, eps1=float(layer.norm1.eps), eps2=float(layer.norm2.eps),
+                has_in=Win is not None, wx_in=offs.get("wx_in", 0), **{k: offs[k] for k in ("wx_o", "wx_1", "wx_2")})
+
+
+def transformer_tail(pack, a, h, out=None, want_qkv=True):
+    """-> (out (M,d), qkv (M,3d) | None); see include/mmb_hip.h: mmb_transformer_tail"""
+    M, d = a.shape
+    if out is None:
+        out = torch.empty(M, d, dtype=torch.float32, device=a.device)
+    qkv = torch.empty(M, 3 * d, dtype=torch.float32, device=a.device) if (want_qkv and pack["has_in"]) else None
+    if _m.PROFILE is not None:
+        macs = d * d + 2 * d * pack["ff"] + (3 * d * d if qkv is not None else 0)
+        _m.PROFILE_META = {"M": M, "flops": 2.0 * macs * M, "bytes": 4.0 * M * (3 * d + (3 * d if qkv is not None else 0))}
+    call("mmb_transformer_tail", M, d, pack["ff"], f32(pack["packed"]), pack["n_vec"], pack["wx_o"], pack["wx_1"],
+         pack["wx_2"], pack["wx_in"], f32(a, "a"), a.stride(0), f32(h, "h"), h.stride(0), out.data_ptr(), out.stride(0),
+         f32(qkv), qkv.stride(0) if qkv is not None else 0, _fl(pack["eps1"]), _fl(pack["eps2"]), stream())
+    _m.PROFILE_META = None
+    return out, qkv
 
 
 def _fill_packed(dst, n_main, flat, gather, gather2, gather_x):

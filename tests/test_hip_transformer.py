@@ -349,3 +349,38 @@ def test_linear_cat_ln(M, K, Nout, path, monkeypatch):
     ref_y, ref_stats = ops.layernorm_fwd(y1, gamma.cuda(), beta.cuda(), 1e-5, want_stats=True)
     close(y, ref_y, rtol=1e-5, atol=1e-5)
     close(stats, ref_stats, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("d,ff,M", [(64, 256, 1000), (128, 256, 4133), (64, 512, 129), (128, 1024, 300)])
+@pytest.mark.parametrize("with_next", [True, False])
+def test_transformer_tail_kernel(d, ff, M, with_next):
+    """mmb_transformer_tail (out_proj + residual + LayerNorm1 + FFN + residual + LayerNorm2 + the next layer's in_proj in
+    one launch, activations in registers) against nn.TransformerEncoderLayer's own arithmetic in float64; the output
+    goes into a column slice of a wider buffer, M is not a multiple of the 128-row tile."""
+    from mmb_hip import fused
+    F = torch.nn.functional
+    torch.manual_seed(d + ff + M)
+    mk = lambda: torch.nn.TransformerEncoderLayer(d_model=d, nhead=4, dim_feedforward=ff, dropout=0.0, batch_first=True)
+    l0, l1 = mk(), mk()
+    for l in (l0, l1):
+        for n, q in l.named_parameters():                      # LayerNorm weights off their 1 / 0 init
+            if "norm" in n:
+                q.data.add_(0.3 * torch.randn_like(q))
+    a, h = torch.randn(M, d), torch.randn(M, d) * 1.5
+    D = lambda t: t.detach().double()
+    h1 = F.layer_norm(D(h) + F.linear(D(a), D(l0.self_attn.out_proj.weight), D(l0.self_attn.out_proj.bias)), (d,),
+                      D(l0.norm1.weight), D(l0.norm1.bias), l0.norm1.eps)
+    f = F.linear(h1, D(l0.linear1.weight), D(l0.linear1.bias)).relu()
+    want = F.layer_norm(h1 + F.linear(f, D(l0.linear2.weight), D(l0.linear2.bias)), (d,), D(l0.norm2.weight),
+                        D(l0.norm2.bias), l0.norm2.eps)
+    want_qkv = F.linear(want, D(l1.self_attn.in_proj_weight), D(l1.self_attn.in_proj_bias))
+    l0, l1 = l0.cuda(), l1.cuda()
+    pack = fused.pack_transformer_tail(l0, l1 if with_next else None)
+    wide = torch.full((M, d + 8), 7.0, device="cuda")
+    out, qkv = fused.transformer_tail(pack, a.cuda(), h.cuda(), out=wide[:, 8:], want_qkv=True)
+    close(out, want, rtol=1e-4, atol=2e-5)
+    assert float((wide[:, :8] - 7.0).abs().max()) == 0.0
+    if with_next:
+        close(qkv, want_qkv, rtol=1e-4, atol=2e-5 * float(want_qkv.abs().max()))
+    else:
+        assert qkv is None

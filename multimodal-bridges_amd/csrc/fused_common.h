@@ -16,7 +16,15 @@ __device__ __forceinline__ void ffor_impl(F&& f, std::integer_sequence<int, Is..
 template <int N, typename F>
 __device__ __forceinline__ void ffor(F&& f) { ffor_impl(f, std::make_integer_sequence<int, N>{}); }
 
-constexpr int FE_THREADS = 256;
+// Waves per workgroup = particle tiles per jet.  The translation unit fused_epic.hip is compiled twice: with 4 waves
+// (N <= 128, two workgroups per CU: every kernel, the training ones included) and, through fused_epic_w5.hip, with 5
+// (N <= 160 -- AOJ's 150-particle clouds --, one workgroup per CU: forward and generation kernels only).
+#ifndef MMB_FE_WAVES
+#define MMB_FE_WAVES 4
+#endif
+constexpr int FE_WAVES = MMB_FE_WAVES;
+constexpr int FE_THREADS = 64 * FE_WAVES;
+static_assert(FE_WAVES == 4 || FE_WAVES == 5, "fused EPiC kernels: 4 or 5 waves per jet");
 
 // A value the optimiser cannot see through: everything derived from it is computed where it is used instead of being
 // hoisted out of the grid-point loop and kept -- i.e. spilled -- across the whole kernel (lane offsets of every matvec
@@ -88,14 +96,14 @@ constexpr int MAX_DESC = 96;        // layer descriptors cached in LDS (S3: 59, 
 struct alignas(16) Lds {
   float temb[128];
   float gcur[64], gskip[64], gnew[64], gcat[64];
-  float partial[4 * 128];
+  float partial[FE_WAVES * 128];
   float gh[128];
   float cvec[128], dvec[128], bvec[128];   // per-layer time vector, global-vector part + bias, second bias
   float pooled[400];                // [mean | 0.01 sum | tail]: the input of fc_glob1 / mlp_global.0 (MV::vidx layout)
   float cw[32 * 4], cb[32];       // continuous embedding weight [Ec][Dc<=4], bias
   float table[8 * 32];            // discrete embedding table [V<=8][Ed<=32]
   float cnt;
-  int red[4];
+  int red[8];
   LDesc desc[MAX_DESC];
 #ifdef MMB_FE_PROF
   unsigned long long tlast;
@@ -640,6 +648,7 @@ struct MV {
   static __device__ __forceinline__ void prefetch(Pre& p, WRsrc R, int wt_off, int b_off, int tid_) {
     const int tid = opaque(tid_);
     const int lane = tid & 63, wave = tid >> 6;
+    if constexpr (FE_WAVES > 4) { if (wave >= 4) return; }     // the per-jet matvecs are laid out over four waves
     const int part = lane & (PARTS - 1), o0 = wave * OW + (lane / PARTS) * VW;
     load_batch<0>(p.w, R, wt_off, part, o0);
     if constexpr (BIAS) p.bv = ld(R, o0 * 4, b_off);
@@ -651,6 +660,7 @@ struct MV {
                                              const float* add, int tid_, float* pre = nullptr) {
     const int tid = opaque(tid_);
     const int lane = tid & 63, wave = tid >> 6;
+    if constexpr (FE_WAVES > 4) { if (wave >= 4) return; }
     const int part = lane & (PARTS - 1), o0 = wave * OW + (lane / PARTS) * VW;
     vec acc;
     ffor<VW>([&](auto ec) { acc[decltype(ec)::v] = 0.0f; });
@@ -716,7 +726,8 @@ __device__ __forceinline__ void pooled_combine(float* pooled, const float* parti
     float v = 0.0f;
     if (j < CMV::ITER && k < 2 * H) {
       const int f = k >= H ? k - H : k;
-      const float sum = (partial[f] + partial[128 + f]) + (partial[256 + f] + partial[384 + f]);
+      float sum = (partial[f] + partial[128 + f]) + (partial[256 + f] + partial[384 + f]);
+      if constexpr (FE_WAVES > 4) sum += partial[512 + f];
       v = k >= H ? sum * 0.01f : sum / cnt;
     } else if (j < CMV::ITER && k < 2 * H + ntail) {
       v = tail[k - 2 * H];

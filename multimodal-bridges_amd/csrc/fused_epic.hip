@@ -26,6 +26,16 @@
 // only what it wrote (no barrier, conflict-free b128) -- and by folding the residual into the
 // accumulator's initial value.  One jet's matvec latency then hides under the other jet's MFMAs.
 
+#ifndef MMB_FE_WAVES
+#define MMB_FE_WAVES 4
+#endif
+#if MMB_FE_WAVES == 5     // second compilation of this file (fused_epic_w5.hip): five waves = up to 160 particles per jet,
+                          // forward and generation entry points only, under names of their own
+#define mmb_fused_epic_forward mmb_fused_epic_forward_w5
+#define mmb_fused_epic_generate mmb_fused_epic_generate_w5
+#define mmb_fused_uni_forward mmb_fused_uni_forward_w5
+#define mmb_fused_uni_generate mmb_fused_uni_generate_w5
+#endif
 #include "fused_common.h"
 #include <stdlib.h>
 
@@ -615,8 +625,8 @@ __device__ __forceinline__ void gather_logits(const f32x16& hd, float (&lg)[DM::
 }
 
 // ---- single forward: heads to HBM (validation / parity / training-forward of eval mode) ----
-template <class DM>
-__global__ void __launch_bounds__(FE_THREADS, 2)
+template <class DM, int NWT = FE_WAVES>        // (NWT: a name of its own per wave count, the two compilations link together)
+__global__ void __launch_bounds__(FE_THREADS, FE_WAVES == 4 ? 2 : 1)
 fused_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64_t* __restrict__ k,
                      const float* __restrict__ temb, int64_t temb_stride, int which, float* __restrict__ head_c,
                      float* __restrict__ head_d) {
@@ -659,8 +669,8 @@ fused_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64_t* __
 }
 
 // ---- training forward: both heads + every activation of the tape to HBM ---------------------
-template <class DM>
-__global__ void __launch_bounds__(FE_THREADS, 2)
+template <class DM, int NWT = FE_WAVES>        // (NWT: a name of its own per wave count, the two compilations link together)
+__global__ void __launch_bounds__(FE_THREADS, FE_WAVES == 4 ? 2 : 1)
 fused_train_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64_t* __restrict__ k,
                            const float* __restrict__ temb, int64_t temb_stride, const SaveSlot* __restrict__ slots,
                            int n_slots, float drop_p, uint64_t seed, uint64_t offset0, float* __restrict__ head_c,
@@ -758,8 +768,8 @@ __device__ __forceinline__ int jump_step(float (&r)[8], int kp, float tt, const 
   return hit >= 0 ? hit : kp;
 }
 
-template <class DM>
-__global__ void __launch_bounds__(FE_THREADS, 2)
+template <class DM, int NWT = FE_WAVES>        // (NWT: a name of its own per wave count, the two compilations link together)
+__global__ void __launch_bounds__(FE_THREADS, FE_WAVES == 4 ? 2 : 1)
 fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* __restrict__ k) {
   __shared__ Lds L;
   __shared__ float4 S[DM::HFT * 4 * FE_THREADS];
@@ -917,8 +927,8 @@ __device__ __forceinline__ void gather8(const f32x16& hd, float (&lg)[8], int la
   }
 }
 
-template <class DM>
-__global__ void __launch_bounds__(FE_THREADS, 2)
+template <class DM, int NWT = FE_WAVES>        // (NWT: a name of its own per wave count, the two compilations link together)
+__global__ void __launch_bounds__(FE_THREADS, FE_WAVES == 4 ? 2 : 1)
 fused_uni_forward_kernel(FusedArgs A, const int64_t* __restrict__ k, const float* __restrict__ temb,
                          int64_t temb_stride, float* __restrict__ head_d) {
   static_assert(DM::V == 8, "fused path is instantiated for vocab_size 8");
@@ -954,8 +964,8 @@ fused_uni_forward_kernel(FusedArgs A, const int64_t* __restrict__ k, const float
 }
 
 // training forward of the discrete-only model: logits + every activation of the tape to HBM
-template <class DM>
-__global__ void __launch_bounds__(FE_THREADS, 2)
+template <class DM, int NWT = FE_WAVES>        // (NWT: a name of its own per wave count, the two compilations link together)
+__global__ void __launch_bounds__(FE_THREADS, FE_WAVES == 4 ? 2 : 1)
 fused_uni_train_forward_kernel(FusedArgs A, const int64_t* __restrict__ k, const float* __restrict__ temb,
                                int64_t temb_stride, const SaveSlot* __restrict__ slots, int n_slots, float drop_p,
                                uint64_t seed, uint64_t offset0, float* __restrict__ head_d) {
@@ -991,8 +1001,8 @@ fused_uni_train_forward_kernel(FusedArgs A, const int64_t* __restrict__ k, const
   }
 }
 
-template <class DM>
-__global__ void __launch_bounds__(FE_THREADS, 2)
+template <class DM, int NWT = FE_WAVES>        // (NWT: a name of its own per wave count, the two compilations link together)
+__global__ void __launch_bounds__(FE_THREADS, FE_WAVES == 4 ? 2 : 1)
 fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
   __shared__ Lds L;
   __shared__ float4 S[DM::HT * 4 * FE_THREADS];
@@ -1040,7 +1050,7 @@ static int stagger_cycles(int dflt) {
 }
 static int check_fused(const char* name, int B, int N, const void* P, const void* D, const void* maskf,
                        const void* counts, int n_desc) {
-  MMB_REQUIRE(B > 0 && N > 0 && N <= 128, "%s: needs 0 < N <= 128 (got B=%d N=%d)", name, B, N);
+  MMB_REQUIRE(B > 0 && N > 0 && N <= 32 * FE_WAVES, "%s: needs 0 < N <= %d (got B=%d N=%d)", name, 32 * FE_WAVES, B, N);
   MMB_REQUIRE(P && D && maskf && counts, "%s: NULL argument", name);
   MMB_REQUIRE(n_desc > 0 && n_desc <= MAX_DESC, "%s: %d layer descriptors, the kernels cache at most %d (fewer blocks, "
               "or the layered path)", name, n_desc, MAX_DESC);
@@ -1054,12 +1064,32 @@ static int n_desc_uni(int nb) { return 4 + 4 * nb + 1; }
 
 using namespace mmb;
 
+#if MMB_FE_WAVES == 4
+// the same entry points compiled for five waves per jet (fused_epic_w5.hip): 128 < N <= 160
+extern "C" int mmb_fused_epic_forward_w5(int, int, int, const float*, const int32_t*, int, int, int, int, int, int, int,
+                                         const float*, const int32_t*, const float*, const int64_t*, const float*, int64_t,
+                                         int, float*, float*, void*);
+extern "C" int mmb_fused_uni_forward_w5(int, int, int, const float*, const int32_t*, int, int, int, const float*,
+                                        const int32_t*, const int64_t*, const float*, int64_t, float*, void*);
+extern "C" int mmb_fused_uni_generate_w5(int, int, int, const float*, const int32_t*, int, int, int, const float*,
+                                         const int32_t*, int64_t*, int, const float*, const float*, const float*, int, float,
+                                         int, float, const float*, uint64_t, uint64_t, void*);
+extern "C" int mmb_fused_epic_generate_w5(int, int, int, const float*, const int32_t*, int, int, int, int, int, int, int,
+                                          const float*, const int32_t*, float*, int64_t*, int, const float*, const float*,
+                                          const float*, int, float, int, float, const float*, uint64_t, uint64_t, int, float,
+                                          const float*, void*);
+#endif
+
 // variant: 0 = S3 dims (Et32 Ec16 Ed16 H64/64/128 G16/16/32), 1 = "mid" dims (Et16 Ec8 Ed8 H32/32/64 G8/8/16)
 extern "C" int mmb_fused_epic_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
                                       int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip, int off_cw, int off_cb,
                                       int off_table, const float* maskf, const int32_t* counts, const float* x,
                                       const int64_t* k, const float* temb, int64_t temb_stride, int which,
                                       float* head_c, float* head_d, void* stream) {
+#if MMB_FE_WAVES == 4
+  if (N > 128) return mmb_fused_epic_forward_w5(variant, B, N, packed, desc, nb_branch, nb_branch1, nb_fused_exec, use_skip, off_cw, off_cb,
+                                                off_table, maskf, counts, x, k, temb, temb_stride, which, head_c, head_d, stream);
+#endif
   int rc = check_fused("mmb_fused_epic_forward", B, N, packed, desc, maskf, counts, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec));
   if (rc) return rc;
   MMB_REQUIRE(variant >= 0 && variant < N_MULTI_VARIANTS, "mmb_fused_epic_forward: unknown variant %d", variant);
@@ -1083,6 +1113,7 @@ extern "C" int mmb_fused_epic_forward(int variant, int B, int N, const float* pa
   return check_launch("mmb_fused_epic_forward");
 }
 
+#if MMB_FE_WAVES == 4
 extern "C" int mmb_fused_epic_train_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
                                             int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip, int off_cw, int off_cb,
                                             int off_table, const float* maskf, const int32_t* counts, const float* x,
@@ -1114,11 +1145,17 @@ extern "C" int mmb_fused_epic_train_forward(int variant, int B, int N, const flo
   return check_launch("mmb_fused_epic_train_forward");
 }
 
+#endif  // MMB_FE_WAVES == 4
+
 // variant: 0 = S2 widths (Et128 Ed128 H128 G16), 1 = Et16 Ed16 H32 G8
 extern "C" int mmb_fused_uni_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
                                      int num_blocks, int use_skip, int off_table, const float* maskf,
                                      const int32_t* counts, const int64_t* k, const float* temb, int64_t temb_stride,
                                      float* head_d, void* stream) {
+#if MMB_FE_WAVES == 4
+  if (N > 128) return mmb_fused_uni_forward_w5(variant, B, N, packed, desc, num_blocks, use_skip, off_table, maskf, counts, k, temb,
+                                               temb_stride, head_d, stream);
+#endif
   int rc = check_fused("mmb_fused_uni_forward", B, N, packed, desc, maskf, counts, n_desc_uni(num_blocks));
   if (rc) return rc;
   MMB_REQUIRE(variant >= 0 && variant < N_UNI_VARIANTS, "mmb_fused_uni_forward: unknown variant %d", variant);
@@ -1139,6 +1176,7 @@ extern "C" int mmb_fused_uni_forward(int variant, int B, int N, const float* pac
   return check_launch("mmb_fused_uni_forward");
 }
 
+#if MMB_FE_WAVES == 4
 extern "C" int mmb_fused_uni_train_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
                                            int num_blocks, int use_skip, int off_table, const float* maskf,
                                            const int32_t* counts, const int64_t* k, const float* temb,
@@ -1169,12 +1207,18 @@ extern "C" int mmb_fused_uni_train_forward(int variant, int B, int N, const floa
   return check_launch("mmb_fused_uni_train_forward");
 }
 
+#endif  // MMB_FE_WAVES == 4
+
 extern "C" int mmb_fused_uni_generate(int variant, int B, int N, const float* packed, const int32_t* desc,
                                       int num_blocks, int use_skip, int off_table, const float* maskf,
                                       const int32_t* counts, int64_t* k, int steps, const float* times,
                                       const float* temb_steps, const float* ctab_steps, int n_ctab, float dt,
                                       int thermo_kind, float gamma, const float* delta_n, uint64_t seed,
                                       uint64_t offset, void* stream) {
+#if MMB_FE_WAVES == 4
+  if (N > 128) return mmb_fused_uni_generate_w5(variant, B, N, packed, desc, num_blocks, use_skip, off_table, maskf, counts, k, steps,
+                                                times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, gamma, delta_n, seed, offset, stream);
+#endif
   int rc = check_fused("mmb_fused_uni_generate", B, N, packed, desc, maskf, counts, n_desc_uni(num_blocks));
   if (rc) return rc;
   MMB_REQUIRE(variant >= 0 && variant < N_UNI_VARIANTS, "mmb_fused_uni_generate: unknown variant %d", variant);
@@ -1195,6 +1239,7 @@ extern "C" int mmb_fused_uni_generate(int variant, int B, int N, const float* pa
   return check_launch("mmb_fused_uni_generate");
 }
 
+#if MMB_FE_WAVES == 4
 // ==================================================================== MultiModalMLP (toy, S1) ====
 // The whole generation loop of the toy hybrid experiment (notebooks/data_toys.ipynb cell 3 inside
 // multimodal_bridge_matching.py:227-259) in ONE launch: the layered path needs 16 launches per grid point and is
@@ -1391,6 +1436,8 @@ extern "C" int mmb_debug_fused_prof(unsigned long long* out16, int reset) {
 }
 #endif
 
+#endif  // MMB_FE_WAVES == 4
+
 extern "C" int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, const int32_t* desc,
                                        int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip, int off_cw, int off_cb,
                                        int off_table, const float* maskf, const int32_t* counts, float* x, int64_t* k,
@@ -1398,6 +1445,11 @@ extern "C" int mmb_fused_epic_generate(int variant, int B, int N, const float* p
                                        const float* ctab_steps, int n_ctab, float dt,
                                        int thermo_kind, float gamma, const float* delta_n, uint64_t seed,
                                        uint64_t offset, int em, float em_sigma, const float* delta_w, void* stream) {
+#if MMB_FE_WAVES == 4
+  if (N > 128) return mmb_fused_epic_generate_w5(variant, B, N, packed, desc, nb_branch, nb_branch1, nb_fused_exec, use_skip, off_cw, off_cb,
+                                                 off_table, maskf, counts, x, k, steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind,
+                                                 gamma, delta_n, seed, offset, em, em_sigma, delta_w, stream);
+#endif
   int rc = check_fused("mmb_fused_epic_generate", B, N, packed, desc, maskf, counts, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec));
   if (rc) return rc;
   MMB_REQUIRE(variant >= 0 && variant < N_MULTI_VARIANTS, "mmb_fused_epic_generate: unknown variant %d", variant);

@@ -41,7 +41,10 @@ def build(force=False, verbose=True):
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
+        deps = [s] + hdrs
+        if s.endswith("_w5.hip"):                       # a second compilation of another source (#include "....hip")
+            deps.append(s[:-7] + ".hip")
+        if force or _stale(o, deps):
             cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -38,13 +38,17 @@ UNI_VARIANTS = {  # (Et, Ed, H, G) -> variant id (csrc/fused_common.h: UniS2 / U
 MAX_TIME_LAYERS = 64
 
 
+MAX_PARTICLES = 160          # five particle tiles per jet (forward / generation); the training kernels: MAX_PARTICLES_TRAIN
+MAX_PARTICLES_TRAIN = 128
+
+
 def eligible_uni(model):
     """Variant id if the model is a discrete-only UniModalEPiC of a compiled width set."""
     cfg = model.config
     e, d = cfg.encoder, cfg.data
     if e.name != "UniModalEPiC" or d.modality != "discrete":
         return None
-    if d.vocab_size != 8 or d.dim_discrete != 1 or (d.max_num_particles or 0) > 128:
+    if d.vocab_size != 8 or d.dim_discrete != 1 or (d.max_num_particles or 0) > MAX_PARTICLES:
         return None
     if e.dim_emb_context_continuous or e.dim_emb_context_discrete:
         return None
@@ -63,7 +67,7 @@ def eligible(model):
     enc = model.encoder
     if not (getattr(enc, "mode_branched", False) and getattr(enc, "mode_fused", False)):
         return None
-    if d.dim_continuous != 3 or d.vocab_size != 8 or (d.max_num_particles or 0) > 128:
+    if d.dim_continuous != 3 or d.vocab_size != 8 or (d.max_num_particles or 0) > MAX_PARTICLES:
         return None
     H0, H1, H2, half = enc.dims
     hl, hg = e.dim_hidden_local, e.dim_hidden_glob

@@ -144,7 +144,7 @@ class MultiModalBridgeMatching(nn.Module):
                 e = self.config.encoder
                 print(f"[mmb] {e.name} with dim_hidden_local={e.dim_hidden_local}, dim_hidden_glob={e.dim_hidden_glob}, "
                       f"dim_emb_time={e.dim_emb_time} is not one of the compiled fused variants "
-                      f"(mmb_hip/fused.py: VARIANTS / UNI_VARIANTS; V = 8, Dc = 3, N <= 128): running the layered "
+                      f"(mmb_hip/fused.py: VARIANTS / UNI_VARIANTS; V = 8, Dc = 3, N <= 160): running the layered "
                       f"HIP path, several times slower in generation and training", file=sys.stderr, flush=True)
         elif self._fused_cache[0] != ver:
             old = self._fused_cache[1]
@@ -156,7 +156,8 @@ class MultiModalBridgeMatching(nn.Module):
 
     def fused_training_available(self):
         """True when training steps of this model run through the fused per-jet kernels (a compiled width set)."""
-        return bool(self.use_fused_training) and self._fused_pack() is not None
+        n = self.config.data.max_num_particles or 0
+        return bool(self.use_fused_training) and self._fused_pack() is not None and n <= fused_epic.MAX_PARTICLES_TRAIN
 
     @staticmethod
     def _pack_serves(pack, state):
@@ -206,7 +207,7 @@ class MultiModalBridgeMatching(nn.Module):
         off = self._next_offset() if (self.training and self.config.encoder.dropout) else 0
         if self._tape is not None and self.use_fused_training:
             pack = self._fused_pack()
-            if pack is not None and self._pack_serves(pack, state):
+            if pack is not None and self._pack_serves(pack, state) and mi.N <= fused_epic.MAX_PARTICLES_TRAIN:
                 from encoders import fused_train                        # taped forward in ONE launch
                 xs = state.continuous.contiguous() if pack["kind"] == "multi" else None
                 ks = state.discrete.contiguous()

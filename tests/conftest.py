@@ -152,7 +152,7 @@ def golden():
     return get
 
 
-MODEL_GOLDENS = ["mm_tiny", "mm_tiny_masked", "mm_mid", "mm_odd", "uni_tiny", "uni_mid", "S3", "S2",
+MODEL_GOLDENS = ["mm_tiny", "mm_tiny_masked", "mm_mid", "mm_odd", "uni_tiny", "uni_mid", "S3", "S2", "S3_n150", "S2_n150",
                  "tr_tiny", "tr_odd", "S4"]
 EPIC_GOLDENS = [n for n in MODEL_GOLDENS if not (n.startswith("tr_") or n == "S4")]
 TRANSFORMER_GOLDENS = ["tr_tiny", "tr_odd", "S4"]

@@ -204,7 +204,7 @@ def test_predict_step_end_to_end(golden):
     assert torch.equal(outs[0].discrete, outs[1].discrete) and torch.equal(outs[0].continuous, outs[1].continuous)
 
 
-@pytest.mark.parametrize("name", ["mm_mid", "S3"])
+@pytest.mark.parametrize("name", ["mm_mid", "S3", "S3_n150"])
 def test_fused_matches_layered(golden, name):
     """The per-jet fused kernels (registers-resident EPiC) against the layered HIP path and the goldens."""
     from tensorclass import TensorMultiModal
@@ -288,7 +288,7 @@ def test_euler_maruyama_generation_vs_oracle(golden, fused):
     assert (p2.continuous[1] - paths.continuous[1]).abs().max() > 1e-3
 
 
-@pytest.mark.parametrize("name", ["uni_mid", "S2"])
+@pytest.mark.parametrize("name", ["uni_mid", "S2", "S2_n150"])
 def test_fused_uni_matches_layered(golden, name):
     """Discrete-only UniModalEPiC (BASELINE configs[1]) through the per-jet fused kernels: logits against the
     golden and the layered path; Philox generation deterministic and statistically like the layered one."""
@@ -671,3 +671,33 @@ def test_gradients_accumulate_across_backward_calls(golden, name, fused):
             want = g1[n] + g2[n]
             close(p.grad, want, rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 1e-8)
             assert float(g2[n].abs().max()) > 0 or float(g1[n].abs().max()) == 0
+
+
+@pytest.mark.parametrize("name,entry", [("S3_n150", "mmb_fused_epic_generate"), ("S2_n150", "mmb_fused_uni_generate")])
+def test_n150_generation_runs_the_fused_five_wave_kernels(golden, name, entry):
+    """AOJ-sized clouds (128 < N <= 160) stay on the single-launch generation path (five waves per jet,
+    csrc/fused_epic_w5.hip): one fused launch per generation and none of the layered path's per-step kernels."""
+    import mmb_hip
+    from tensorclass import TensorMultiModal
+    from datamodules.datasets import DataCoupling
+    g = golden(name)
+    model = build(g, num_timesteps=7)
+    B, N = 6, 150
+    tgt = TensorMultiModal(None, None if name.startswith("S2") else torch.zeros(B, N, 3, device="cuda"),
+                           torch.zeros(B, N, 1, dtype=torch.int64, device="cuda"),
+                           torch.ones(B, N, 1, dtype=torch.int64, device="cuda"))
+    model.manual_seed(3)
+    mmb_hip.PROFILE = []
+    try:
+        paths, _ = model.predict_step(DataCoupling(TensorMultiModal(), tgt, None), 0, to_cpu=False)
+        torch.cuda.synchronize()
+        names = [r[0] for r in mmb_hip.PROFILE]
+    finally:
+        mmb_hip.PROFILE = None
+    # (mmb_linear_cat appears a few times: the per-grid-point time-vector table is built with it, once per weight version)
+    layered = {"mmb_meansum_pool", "mmb_euler_step", "mmb_rate_tauleap"} & set(names)
+    assert names.count(entry) == 1 and not layered, (layered, names.count(entry))
+    assert int(paths.discrete[1].min()) >= 0 and int(paths.discrete[1].max()) < 8
+    if paths.continuous is not None:
+        assert torch.isfinite(paths.continuous[1]).all()
+    assert not model.fused_training_available()              # the training kernels stop at 128 particles

@@ -729,6 +729,8 @@ def main():
     golden_model("uni_mid", V["uni_mid"], 4, 16, "random", True, seed=8, steps_list=(10, 100))
     golden_model("S3", V["S3"], 2, 128, "random", False, seed=9, steps_list=(5, 100))
     golden_model("S2", V["S2"], 2, 128, "random", False, seed=10, steps_list=(5, 100))
+    golden_model("S3_n150", V["S3"], 2, 150, "random", False, seed=14, steps_list=(5, 100))      # AOJ's 150-particle clouds
+    golden_model("S2_n150", V["S2"], 2, 150, "random", False, seed=15, steps_list=(5, 100))
     golden_model("tr_tiny", V["tr_tiny"], 4, 16, "random_full", True, seed=11, steps_list=(10, 100), explicit_source=True)
     golden_model("tr_odd", V["tr_odd"], 3, 11, "random_full", True, seed=12, explicit_source=True)
     golden_model("S4", V["S4"], 2, 150, "random_full", False, seed=13, steps_list=(5, 100), explicit_source=True)
@@ -751,6 +753,12 @@ if __name__ == "__main__":
         V = variants()
         golden_model("tr_tiny", V["tr_tiny"], 4, 16, "random_full", True, seed=11, steps_list=(10, 100), explicit_source=True)
         golden_model("S4", V["S4"], 2, 150, "random_full", False, seed=13, steps_list=(5, 100), explicit_source=True)
+    elif len(sys.argv) > 1 and sys.argv[1] == "n150":                # the EPiC models at AOJ's 150 particles per jet
+        _install_stubs()
+        torch.set_num_threads(8)
+        V = variants()
+        golden_model("S3_n150", V["S3"], 2, 150, "random", False, seed=14, steps_list=(5, 100))
+        golden_model("S2_n150", V["S2"], 2, 150, "random", False, seed=15, steps_list=(5, 100))
     elif len(sys.argv) > 1 and sys.argv[1] == "postprocess":
         _install_stubs()
         golden_postprocess()

@@ -470,8 +470,8 @@ int mmb_toy_generate(int B, int N, int H, int Dc, int V, const float* table, con
  * six bf16 x bf16 partial products accumulated in fp32, results are fp32 results).  Compiled width sets: variant 0: S3
  * (Et32 Ec16 Ed16 H64/64/128 G16/16/32); 1: Et16 Ec8 Ed8 H32/32/64 G8/8/16; 2: Et64 Ec32 Ed32 H64/64/128 G32/32/64;
  * 3: Et32 Ec16 Ed16 H32/32/64 G16/16/32.  nb_branch / nb_branch1: EPiC layers of the continuous / discrete branch
- * encoder (they may differ), nb_fused_exec: executed layers of the fused encoder (K2).  N <= 160 (forward, generation; N > 128 runs the five-wave
- * compilation of the same kernels, one workgroup per CU) or N <= 128 (training entry points), Dc = 3, V = 8.  temb: (B,Et) with row stride
+ * encoder (they may differ), nb_fused_exec: executed layers of the fused encoder (K2).  N <= 160 (N > 128 runs the five-wave compilation of the
+ * same kernels, one workgroup per CU), Dc = 3, V = 8.  temb: (B,Et) with row stride
  * temb_stride (0 = one row shared by all jets).  which: 0 continuous head, 1 discrete head, 2 both. */
 int mmb_fused_epic_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
                            int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip,
@@ -554,7 +554,7 @@ int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, cons
  * The projection sees cat[t, t, trunc(k_emb*mask)]; both time blocks are summed on the host.
  * variant 0: Et128 Ed128 H128 G16 (configs/S2_discrete.yaml); 1: Et16 Ed16 H32 G8; 2: Et64 Ed64 H64 G16;
  * 3: Et32 Ed32 H32 G16.
- * N <= 160 (training entry points: 128), V = 8.  head_d: (B,N,8) logits. */
+ * N <= 160, V = 8.  head_d: (B,N,8) logits. */
 int mmb_fused_uni_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
                           int num_blocks, int use_skip, int off_table,
                           const float* maskf, const int32_t* counts, const int64_t* k,

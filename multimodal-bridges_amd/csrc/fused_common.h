@@ -300,6 +300,7 @@ struct WaveMV {
   static __device__ __forceinline__ void run(const float* __restrict__ WT, const float* __restrict__ bias, VFn&& vfn,
                                              float* out, const float* add, int tid, float* pre = nullptr) {
     const int lane = tid & 63, wave = tid >> 6;
+    if (FE_WAVES == 4 || wave < 4) {                       // (five-wave build: the matvec is laid out over four waves)
     const int og = lane & (G - 1), part = lane / G;
     const int o0 = wave * OW + og * VW;
     const vec* wp = reinterpret_cast<const vec*>(WT + o0);
@@ -340,6 +341,7 @@ struct WaveMV {
         if (add) t += add[o0 + e];
         out[o0 + e] = t;
       });
+    }
     }
     __syncthreads();
   }
@@ -479,6 +481,9 @@ struct WRing {
 };
 // fragment g of the matrix at woff -> one ring slot (three planes, 3 KiB per wave)
 __device__ __forceinline__ void frag_load(Frag16& f, WRsrc R, int woff, int g, int lane16) {
+#ifdef MMB_WHATIF_HOTFRAG      // developer timing build (wrong results on purpose): every fragment load hits the same 3 KiB
+  g = 0;
+#endif
 #ifdef MMB_WHATIF_ONEPLANE     // developer timing build (wrong results on purpose): one third of the weight-fragment bytes
   f.p[0] = wload(R, woff, (g * 3) * 64, lane16);
   f.p[1] = f.p[0];

@@ -35,6 +35,8 @@
 #define mmb_fused_epic_generate mmb_fused_epic_generate_w5
 #define mmb_fused_uni_forward mmb_fused_uni_forward_w5
 #define mmb_fused_uni_generate mmb_fused_uni_generate_w5
+#define mmb_fused_epic_train_forward mmb_fused_epic_train_forward_w5
+#define mmb_fused_uni_train_forward mmb_fused_uni_train_forward_w5
 #endif
 #include "fused_common.h"
 #include <stdlib.h>
@@ -1078,6 +1080,12 @@ extern "C" int mmb_fused_epic_generate_w5(int, int, int, const float*, const int
                                           const float*, const int32_t*, float*, int64_t*, int, const float*, const float*,
                                           const float*, int, float, int, float, const float*, uint64_t, uint64_t, int, float,
                                           const float*, void*);
+extern "C" int mmb_fused_epic_train_forward_w5(int, int, int, const float*, const int32_t*, int, int, int, int, int, int, int,
+                                               const float*, const int32_t*, const float*, const int64_t*, const float*,
+                                               int64_t, const void*, int, float, uint64_t, uint64_t, float*, float*, void*);
+extern "C" int mmb_fused_uni_train_forward_w5(int, int, int, const float*, const int32_t*, int, int, int, const float*,
+                                              const int32_t*, const int64_t*, const float*, int64_t, const void*, int, float,
+                                              uint64_t, uint64_t, float*, void*);
 #endif
 
 // variant: 0 = S3 dims (Et32 Ec16 Ed16 H64/64/128 G16/16/32), 1 = "mid" dims (Et16 Ec8 Ed8 H32/32/64 G8/8/16)
@@ -1113,13 +1121,17 @@ extern "C" int mmb_fused_epic_forward(int variant, int B, int N, const float* pa
   return check_launch("mmb_fused_epic_forward");
 }
 
-#if MMB_FE_WAVES == 4
 extern "C" int mmb_fused_epic_train_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
                                             int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip, int off_cw, int off_cb,
                                             int off_table, const float* maskf, const int32_t* counts, const float* x,
                                             const int64_t* k, const float* temb, int64_t temb_stride,
                                             const void* slots, int n_slots, float drop_p, uint64_t seed,
                                             uint64_t offset0, float* head_c, float* head_d, void* stream) {
+#if MMB_FE_WAVES == 4
+  if (N > 128) return mmb_fused_epic_train_forward_w5(variant, B, N, packed, desc, nb_branch, nb_branch1, nb_fused_exec, use_skip,
+                                                      off_cw, off_cb, off_table, maskf, counts, x, k, temb, temb_stride, slots,
+                                                      n_slots, drop_p, seed, offset0, head_c, head_d, stream);
+#endif
   int rc = check_fused("mmb_fused_epic_train_forward", B, N, packed, desc, maskf, counts, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec));
   if (rc) return rc;
   MMB_REQUIRE(variant >= 0 && variant < N_MULTI_VARIANTS, "mmb_fused_epic_train_forward: unknown variant %d", variant);
@@ -1144,8 +1156,6 @@ extern "C" int mmb_fused_epic_train_forward(int variant, int B, int N, const flo
   }
   return check_launch("mmb_fused_epic_train_forward");
 }
-
-#endif  // MMB_FE_WAVES == 4
 
 // variant: 0 = S2 widths (Et128 Ed128 H128 G16), 1 = Et16 Ed16 H32 G8
 extern "C" int mmb_fused_uni_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
@@ -1176,12 +1186,15 @@ extern "C" int mmb_fused_uni_forward(int variant, int B, int N, const float* pac
   return check_launch("mmb_fused_uni_forward");
 }
 
-#if MMB_FE_WAVES == 4
 extern "C" int mmb_fused_uni_train_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
                                            int num_blocks, int use_skip, int off_table, const float* maskf,
                                            const int32_t* counts, const int64_t* k, const float* temb,
                                            int64_t temb_stride, const void* slots, int n_slots, float drop_p,
                                            uint64_t seed, uint64_t offset0, float* head_d, void* stream) {
+#if MMB_FE_WAVES == 4
+  if (N > 128) return mmb_fused_uni_train_forward_w5(variant, B, N, packed, desc, num_blocks, use_skip, off_table, maskf, counts,
+                                                     k, temb, temb_stride, slots, n_slots, drop_p, seed, offset0, head_d, stream);
+#endif
   int rc = check_fused("mmb_fused_uni_train_forward", B, N, packed, desc, maskf, counts, n_desc_uni(num_blocks));
   if (rc) return rc;
   MMB_REQUIRE(variant >= 0 && variant < N_UNI_VARIANTS, "mmb_fused_uni_train_forward: unknown variant %d", variant);
@@ -1206,8 +1219,6 @@ extern "C" int mmb_fused_uni_train_forward(int variant, int B, int N, const floa
   }
   return check_launch("mmb_fused_uni_train_forward");
 }
-
-#endif  // MMB_FE_WAVES == 4
 
 extern "C" int mmb_fused_uni_generate(int variant, int B, int N, const float* packed, const int32_t* desc,
                                       int num_blocks, int use_skip, int off_table, const float* maskf,

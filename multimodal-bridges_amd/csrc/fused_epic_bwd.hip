@@ -10,6 +10,13 @@
 // Rows of masked particles: the loss gradient is 0 there, every per-particle op is row-wise and the
 // pooling gradient is multiplied by the mask, so dZ is 0 on them in every layer -- masked and unmasked
 // column sums coincide and one butterfly per layer serves both the time and the global-vector segment.
+#ifndef MMB_FE_WAVES
+#define MMB_FE_WAVES 4
+#endif
+#if MMB_FE_WAVES == 5     // second compilation (fused_epic_bwd_w5.hip): five waves per jet, N <= 160
+#define mmb_fused_epic_train_backward mmb_fused_epic_train_backward_w5
+#define mmb_fused_uni_train_backward mmb_fused_uni_train_backward_w5
+#endif
 #include "fused_common.h"
 
 namespace mmb {
@@ -27,7 +34,7 @@ struct alignas(16) LdsB {
   float dpool[256];
   float cpool[128];
   float svec[128];
-  float partial[4 * 128];
+  float partial[FE_WAVES * 128];
   float cnt;
 };
 
@@ -83,7 +90,8 @@ __device__ __forceinline__ void colsum(const f32x16 (&dz)[HT], LdsB& LB, Slots& 
   __syncthreads();
   float* dst = sl.row(W);                                // W: true width of the layer (the slot's row length)
   if (tid < 32 * HT) {
-    const float s = (LB.partial[tid] + LB.partial[128 + tid]) + (LB.partial[256 + tid] + LB.partial[384 + tid]);
+    float s = (LB.partial[tid] + LB.partial[128 + tid]) + (LB.partial[256 + tid] + LB.partial[384 + tid]);
+    if constexpr (FE_WAVES > 4) s += LB.partial[512 + tid];
     LB.svec[tid] = s;
     if (dst != nullptr && tid < W) dst[tid] = s;
   }
@@ -270,8 +278,8 @@ struct EpicB {
 // (rows, 2HB: dZ of the branch output layers), [3] d temb (B, ET); then in the order the kernel walks:
 // heads (continuous, discrete): d_head, pre, dz, S;  fused encoder: S_out, layers last..first;
 // branches (continuous, discrete): S_out, layers last..first, projection (+ d_in for the continuous one).
-template <class DM>
-__global__ void __launch_bounds__(FE_THREADS, 2)
+template <class DM, int NWT = FE_WAVES>
+__global__ void __launch_bounds__(FE_THREADS, FE_WAVES == 4 ? 2 : 1)
 fused_train_backward_kernel(BwdArgs A) {
   __shared__ LdsB LB;
   __shared__ float4 S[DM::HFT * 4 * FE_THREADS];
@@ -398,8 +406,8 @@ fused_train_backward_kernel(BwdArgs A) {
 // ---- discrete-only model (UniModalEPiC): one encoder with projection whose output layer emits the logits.
 // Slot table: [0] d temb (B,ET); then d logits (rows,8), column sums of the output layer (B,8), layers
 // last..first, projection.
-template <class DM>
-__global__ void __launch_bounds__(FE_THREADS, 2)
+template <class DM, int NWT = FE_WAVES>
+__global__ void __launch_bounds__(FE_THREADS, FE_WAVES == 4 ? 2 : 1)
 fused_uni_train_backward_kernel(BwdArgs A) {
   static_assert(DM::V == 8, "fused path is instantiated for vocab_size 8");
   __shared__ LdsB LB;
@@ -451,11 +459,22 @@ fused_uni_train_backward_kernel(BwdArgs A) {
 
 using namespace mmb;
 
+#if MMB_FE_WAVES == 4
+extern "C" int mmb_fused_uni_train_backward_w5(int, int, int, const float*, const int32_t*, int, int, const float*,
+                                               const int32_t*, const void*, int, float, uint64_t, uint64_t, void*);
+extern "C" int mmb_fused_epic_train_backward_w5(int, int, int, const float*, const int32_t*, int, int, int, int, const float*,
+                                                const int32_t*, const void*, int, float, uint64_t, uint64_t, void*);
+#endif
+
 extern "C" int mmb_fused_uni_train_backward(int variant, int B, int N, const float* packed_bwd, const int32_t* desc_bwd,
                                             int num_blocks, int use_skip, const float* maskf, const int32_t* counts,
                                             const void* slots, int n_slots, float drop_p, uint64_t seed,
                                             uint64_t offset0, void* stream) {
-  MMB_REQUIRE(B > 0 && N > 0 && N <= 128, "mmb_fused_uni_train_backward: needs 0 < N <= 128 (got B=%d N=%d)", B, N);
+#if MMB_FE_WAVES == 4
+  if (N > 128) return mmb_fused_uni_train_backward_w5(variant, B, N, packed_bwd, desc_bwd, num_blocks, use_skip, maskf, counts,
+                                                      slots, n_slots, drop_p, seed, offset0, stream);
+#endif
+  MMB_REQUIRE(B > 0 && N > 0 && N <= 32 * FE_WAVES, "mmb_fused_uni_train_backward: needs 0 < N <= %d (got B=%d N=%d)", 32 * FE_WAVES, B, N);
   MMB_REQUIRE(packed_bwd && desc_bwd && maskf && counts && slots, "mmb_fused_uni_train_backward: NULL argument");
   MMB_REQUIRE(variant >= 0 && variant < N_UNI_VARIANTS, "mmb_fused_uni_train_backward: unknown variant %d", variant);
   MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_fused_uni_train_backward: dropout p=%f outside [0,1)", drop_p);
@@ -479,7 +498,11 @@ extern "C" int mmb_fused_epic_train_backward(int variant, int B, int N, const fl
                                              const float* maskf,
                                              const int32_t* counts, const void* slots, int n_slots, float drop_p,
                                              uint64_t seed, uint64_t offset0, void* stream) {
-  MMB_REQUIRE(B > 0 && N > 0 && N <= 128, "mmb_fused_epic_train_backward: needs 0 < N <= 128 (got B=%d N=%d)", B, N);
+#if MMB_FE_WAVES == 4
+  if (N > 128) return mmb_fused_epic_train_backward_w5(variant, B, N, packed_bwd, desc_bwd, nb_branch, nb_branch1, nb_fused_exec,
+                                                       use_skip, maskf, counts, slots, n_slots, drop_p, seed, offset0, stream);
+#endif
+  MMB_REQUIRE(B > 0 && N > 0 && N <= 32 * FE_WAVES, "mmb_fused_epic_train_backward: needs 0 < N <= %d (got B=%d N=%d)", 32 * FE_WAVES, B, N);
   MMB_REQUIRE(packed_bwd && desc_bwd && maskf && counts && slots, "mmb_fused_epic_train_backward: NULL argument");
   MMB_REQUIRE(variant >= 0 && variant < N_MULTI_VARIANTS, "mmb_fused_epic_train_backward: unknown variant %d", variant);
   MMB_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "mmb_fused_epic_train_backward: dropout p=%f outside [0,1)", drop_p);

@@ -29,6 +29,7 @@ class _Plan:
         self.drop_p, self.offset0, self.off = drop_p, offset0, offset0
         self.enc = []                # per encoder (continuous, discrete, fused): dict(proj, layers, out)
         self.heads = []
+        self.sign_words = 2 * 64 * (4 if N <= 128 else 5)     # floats: the kernels run 4 or 5 waves per jet
 
     def slot(self, t):
         self.slots.append(_slot(t))
@@ -86,10 +87,10 @@ def _encoder(pl, enc, tseg, x_local, x_global, out, out_slot=True):
         p, off = pl.next_offset()
         g2 = pl.linear(ly.fc_glob2, 1, [(gh, SEG_ROW)], res1=x_global, post="lrelu", res2=skip_g, y1=g_new, y2=g_out,
                        p=p, off=off)
-        sgn_lh = pl.jets(512)                    # 256 x 64-bit words per jet: sign bits for the reverse kernel
+        sgn_lh = pl.jets(pl.sign_words)          # one 64-bit word per thread of the jet's workgroup: sign bits for the reverse kernel
         lh = pl.rows(ly.fc_loc1.dim_out)
         l1 = pl.linear(ly.fc_loc1, N, [tseg, (x_local, SEG_ROW), (g_new, SEG_JET)], act="lrelu", y1=lh)
-        sgn_y1 = pl.jets(512)
+        sgn_y1 = pl.jets(pl.sign_words)
         l_out = pl.rows(H)
         p, off = pl.next_offset()
         l2 = pl.linear(ly.fc_loc2, N, [(lh, SEG_ROW)], res1=x_local, post="lrelu", res2=skip_l, y2=l_out, p=p, off=off)

@@ -38,8 +38,8 @@ UNI_VARIANTS = {  # (Et, Ed, H, G) -> variant id (csrc/fused_common.h: UniS2 / U
 MAX_TIME_LAYERS = 64
 
 
-MAX_PARTICLES = 160          # five particle tiles per jet (forward / generation); the training kernels: MAX_PARTICLES_TRAIN
-MAX_PARTICLES_TRAIN = 128
+MAX_PARTICLES = 160          # five particle tiles per jet (N > 128: the five-wave compilation of every fused kernel)
+MAX_PARTICLES_TRAIN = 160
 
 
 def eligible_uni(model):

@@ -330,7 +330,7 @@ def test_fused_uni_matches_layered(golden, name):
     assert (ha / ha.sum() - hb / hb.sum()).abs().max() < 0.03
 
 
-@pytest.mark.parametrize("name", ["mm_mid", "S3", "uni_mid", "S2"])
+@pytest.mark.parametrize("name", ["mm_mid", "S3", "uni_mid", "S2", "S3_n150", "S2_n150"])
 @pytest.mark.parametrize("drop", [0.0, 0.2])
 def test_fused_training_matches_layered(golden, name, drop):
     """Training step through the fused per-jet kernels (ONE forward launch that saves the tape, ONE backward launch
@@ -700,4 +700,4 @@ def test_n150_generation_runs_the_fused_five_wave_kernels(golden, name, entry):
     assert int(paths.discrete[1].min()) >= 0 and int(paths.discrete[1].max()) < 8
     if paths.continuous is not None:
         assert torch.isfinite(paths.continuous[1]).all()
-    assert not model.fused_training_available()              # the training kernels stop at 128 particles
+    assert model.fused_training_available()                  # the training kernels have the five-wave build too

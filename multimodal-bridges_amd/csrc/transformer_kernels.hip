@@ -54,12 +54,39 @@ __device__ __forceinline__ float attn_keep1(const AttnDrop& d, int64_t bh, int N
   return ((attn_keep4(d, bh, N, q, j >> 2) >> (j & 3)) & 1u) ? d.inv_keep : 0.0f;
 }
 
+// Uniform keys.  The reference restricts the keys to the PADDED slots (quirk Q4), and in its model every padded slot of
+// a jet carries the same row in every layer (all inputs are multiplied by the mask: embedder.py:63-97), so in eval mode
+// all valid keys of a (jet, head) have bit-identical K and V rows: the scores of a query are then all equal, the softmax
+// is uniform and the output is that one V row whatever the query.  The forward kernels TEST this on the staged rows
+// (nk * dh compares against row 0, one block-wide vote) and, when it holds and no log-sum-exp is asked for, write the
+// row out for every query instead of walking the keys; any other input takes the general path in the same launch.
+// K, V rows of pitch P in LDS; returns true for nk > 0 identical rows.
+__device__ inline bool keys_uniform(const float* Ks, const float* Vs, int nk, int dh, int P) {
+  bool same = nk > 0;
+  for (int i = threadIdx.x; i < nk * dh; i += blockDim.x) {
+    const int j = i / dh, d = i - j * dh;
+    same = same && __float_as_uint(Ks[j * P + d]) == __float_as_uint(Ks[d]) &&
+           __float_as_uint(Vs[j * P + d]) == __float_as_uint(Vs[d]);
+  }
+  return __syncthreads_and(same ? 1 : 0) != 0;
+}
+__device__ inline void broadcast_row(const float* Vs, int N, int dh, float* __restrict__ o, int64_t out_ld) {
+  for (int i = threadIdx.x; i < N * dh; i += blockDim.x) {
+    const int q = i / dh, d = i - q * dh;
+    o[(int64_t)q * out_ld + d] = Vs[d];
+  }
+}
+static bool attn_uniform_enabled() {
+  static const bool on = [] { const char* e = getenv("MMB_ATTN_UNIFORM"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 // out[q, h*dh + d] = sum_j softmax_j(scale * q.k_j) v_j over the valid keys j;  lse[(b*nh+h)*N + q] = log sum exp
 template <int DHP, bool DROP>
 __global__ void __launch_bounds__(256)
 attn_fwd_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int64_t ld,
                 const float* __restrict__ maskf, int valid_is_zero, float scale, float* __restrict__ out,
-                int64_t out_ld, float* __restrict__ lse, AttnDrop drop) {
+                int64_t out_ld, float* __restrict__ lse, AttnDrop drop, int uniform_ok) {
   extern __shared__ float sm[];
   const int b = blockIdx.x / nh, h = blockIdx.x - b * nh;
   int* idx = reinterpret_cast<int*>(sm);
@@ -75,6 +102,12 @@ attn_fwd_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int
     Vs[i] = d < dh ? base[row + 2 * H + d] : 0.0f;
   }
   __syncthreads();
+  if constexpr (!DROP) {
+    if (uniform_ok && lse == nullptr && keys_uniform(Ks, Vs, nk, dh, DHP)) {
+      broadcast_row(Vs, N, dh, out + (int64_t)b * N * out_ld + h * dh, out_ld);
+      return;
+    }
+  }
   for (int q = threadIdx.x; q < N; q += blockDim.x) {
     float qv[DHP], acc[DHP];
 #pragma unroll
@@ -404,7 +437,7 @@ template <int DH, bool VEC, bool DROP>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DH == 16 ? 8 : 6)))
 attn_fwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int64_t ld,
                      const float* __restrict__ maskf, int valid_is_zero, float scale, float* __restrict__ out,
-                     int64_t out_ld, float* __restrict__ lse, AttnDrop drop) {
+                     int64_t out_ld, float* __restrict__ lse, AttnDrop drop, int uniform_ok) {
   constexpr int P = DH + 4, HD = DH / 2, DT = (DH + 31) / 32;
   extern __shared__ float sm[];
   int b, h;
@@ -423,6 +456,12 @@ attn_fwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv
   const int nk = stage_keys<DH, VEC>(maskf + (int64_t)b * N, N, valid_is_zero, base + H, base + 2 * H, ld, dh, idx, pos,
                                      nk_sh, Ks, Vs);
   const int nkp = (nk + 31) & ~31;
+  if constexpr (!DROP) {
+    if (uniform_ok && lse == nullptr && keys_uniform(Ks, Vs, nk, dh, P)) {
+      broadcast_row(Vs, N, dh, out + (int64_t)b * N * out_ld + h * dh, out_ld);
+      return;
+    }
+  }
   for (int qt = wave * 32; qt < N; qt += nwaves * 32) {
     const int q = qt + col;
     if (qt != wave * 32)
@@ -928,12 +967,13 @@ static int attention_fwd_impl(const char* fn, int B, int N, int H, int nheads, c
   dim3 grid(B * nheads), block(N <= 64 ? 64 : N <= 128 ? 128 : N <= 192 ? 192 : 256);
   hipStream_t st = as_stream(stream);
   const float scale = 1.0f / sqrtf((float)dh);
+  const int uniform_ok = attn_uniform_enabled() ? 1 : 0;
   if (mfma) {
     block = dim3(64 * ((N + 31) / 32));
     const bool vec = dh % 4 == 0 && qkv_ld % 4 == 0 && out_ld % 4 == 0 && aligned16(qkv) && aligned16(out);
 #define MMB_FWD_MFMA(DHV, VECV, DROPV)                                                                                \
   hipLaunchKernelGGL((attn_fwd_mfma_kernel<DHV, VECV, DROPV>), grid, block, lds, st, N, H, nheads, dh, qkv, qkv_ld,    \
-                     maskf, valid_is_zero, scale, out, out_ld, lse, drop)
+                     maskf, valid_is_zero, scale, out, out_ld, lse, drop, uniform_ok)
 #define MMB_FWD_MFMA2(DHV, VECV) do { if (drop.p > 0.0f) MMB_FWD_MFMA(DHV, VECV, true); else MMB_FWD_MFMA(DHV, VECV, false); } while (0)
     if (dh <= 16) { if (vec) MMB_FWD_MFMA2(16, true); else MMB_FWD_MFMA2(16, false); }
     else { if (vec) MMB_FWD_MFMA2(32, true); else MMB_FWD_MFMA2(32, false); }
@@ -941,7 +981,8 @@ static int attention_fwd_impl(const char* fn, int B, int N, int H, int nheads, c
 #undef MMB_FWD_MFMA
     return check_launch(fn);
   }
-  MMB_ATTN_DISPATCH(attn_fwd_kernel, N, H, nheads, dh, qkv, qkv_ld, maskf, valid_is_zero, scale, out, out_ld, lse, drop);
+  MMB_ATTN_DISPATCH(attn_fwd_kernel, N, H, nheads, dh, qkv, qkv_ld, maskf, valid_is_zero, scale, out, out_ld, lse, drop,
+                    uniform_ok);
   return check_launch(fn);
 }
 

@@ -384,3 +384,29 @@ def test_transformer_tail_kernel(d, ff, M, with_next):
         close(qkv, want_qkv, rtol=1e-4, atol=2e-5 * float(want_qkv.abs().max()))
     else:
         assert qkv is None
+
+
+@pytest.mark.parametrize("B,N,H,nh", [(5, 16, 8, 2), (4, 150, 64, 4), (3, 150, 128, 4), (2, 70, 128, 2)])
+@pytest.mark.parametrize("path", ["mfma", "valu"])
+def test_attention_uniform_keys(B, N, H, nh, path, monkeypatch):
+    """What the reference's model feeds the attention in eval mode: every valid key (= padded slot, quirk Q4) of a jet
+    carries the same row.  The forward kernels detect that on the staged rows and write the one V row out for every
+    query; the result must be the general algorithm's (float64 restatement), also for the jets whose keys are NOT all
+    alike in the same launch (jet 0 gets one perturbed key) and for a jet without any valid key."""
+    from mmb_hip import ops
+    monkeypatch.setenv("MMB_ATTN_PATH", path)
+    g = torch.Generator().manual_seed(B * 77 + N + H)
+    qkv = torch.randn(B, N, 3 * H, generator=g)
+    mask = make_mask(B, N, g)
+    pad = mask == 0                                            # the valid keys
+    row = torch.randn(B, 1, 3 * H, generator=g)
+    qkv = torch.where(pad[..., None], row.expand(B, N, 3 * H), qkv)
+    if int(pad[0].sum()) >= 2:                                 # one odd key in jet 0: that jet takes the general path
+        j = int(pad[0].nonzero()[-1])
+        qkv[0, j, H:] += 0.5
+    want = ref_attention(qkv.double(), mask, nh, True)
+    mi = ops.mask_prepare(mask.cuda())
+    out = ops.attention_fwd(qkv.reshape(B * N, 3 * H).cuda(), mi, nh, valid_is_zero=True)
+    close(out.view(B, N, H), want, rtol=1e-5, atol=1e-6 * float(want.abs().max()))
+    out2, lse = ops.attention_fwd(qkv.reshape(B * N, 3 * H).cuda(), mi, nh, valid_is_zero=True, want_lse=True)
+    close(out2, out, rtol=1e-5, atol=1e-6 * float(want.abs().max()))      # (with lse: the general path)

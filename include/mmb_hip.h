@@ -429,11 +429,12 @@ int mmb_attention_dropout_mask(int B, int N, int nheads, const float* maskf, int
  * beta2 | b1 | b_in] followed by the weights in MFMA fragment order, three bf16 planes per fp32 value (INTEGRATION.md,
  * "Parameter block"; mmb_hip/fused.py: pack_transformer_tail): W_o, then per 64-unit FFN chunk c W1[64c:64c+64, :] (block
  * wx_1) and W2[:, 64c:64c+64] (block wx_2), then the three d x d blocks of in_proj; wx_*: float offsets from the start of
- * the fragment part.  All row strides multiples of 4 floats, all pointers 16-byte aligned.  Results are fp32 results
+ * the fragment part.  a_idx: NULL, or per row the row of `a` to use (< 0: zeros) -- the compacted inference path reads one V
+ * row per jet straight out of the qkv buffer.  All row strides multiples of 4 floats, all pointers 16-byte aligned.  Results are fp32 results
  * (exact three-plane split, six partial products). */
 int mmb_transformer_tail(int64_t M, int d, int ff, const float* packed, int n_vec, int wx_o, int wx_1, int wx_2, int wx_in,
                          const float* a, int64_t a_ld, const float* h, int64_t h_ld, float* out, int64_t out_ld, float* qkv,
-                         int64_t qkv_ld, float eps1, float eps2, void* stream);
+                         int64_t qkv_ld, float eps1, float eps2, const int32_t* a_idx, void* stream);
 /* nn.LayerNorm over the last dim (norm1 / norm2 of the encoder layer; biased variance, eps inside the root):
  * y = (x - mean)/sqrt(var + eps) * gamma + beta; stats (M,2) | NULL receives (mean, 1/sqrt(var+eps)) per row. */
 int mmb_layernorm_fwd(int64_t M, int D, const float* x, int64_t x_ld, const float* gamma, const float* beta, float eps,

@@ -30,6 +30,8 @@ struct TailArgs {
   float* qkv; int64_t qkv_ld;  // NULL: no in_proj
   float eps1, eps2;
   int n_chunks;                // ff / 64
+  const int32_t* a_idx;        // NULL, or per row the row of `a` to read (< 0: a zero row) -- the attention output of the
+                               // compacted inference path is one V row per jet, read in place from the qkv buffer
 };
 
 // vector part, float offsets (d = model width, ff = FFN width): b_o, gamma1, beta1, b2, gamma2, beta2 (d each), b1 (ff),
@@ -136,7 +138,11 @@ transformer_tail_kernel(TailArgs A) {
   f32x16 x[DT];
   {
     f32x16 a[DT];
-    load_rows<DT>(a, A.a, A.a_ld, row, half);
+    int64_t arow = row;
+    if (A.a_idx != nullptr) arow = A.a_idx[row];
+    load_rows<DT>(a, A.a, A.a_ld, arow < 0 ? 0 : arow, half);
+    if (arow < 0) ffor<DT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+      ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; a[t][r] = 0.0f; }); });
     load_rows<DT>(x, A.h, A.h_ld, row, half);
     __syncthreads();                                          // the vectors are in LDS
     add_vec<DT>(x, vec + V::BO, half);                        // x = h + b_o + W_o a
@@ -182,10 +188,11 @@ static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 // d: model width (64 or 128), ff: FFN width (multiple of 64, <= 1024).  packed: n_vec floats [b_o | gamma1 | beta1 | b2 |
 // gamma2 | beta2 | b1 | b_in] followed by the weight fragments; wx_*: float offsets of the fragment blocks RELATIVE TO THE
-// FRAGMENT PART (after the vectors).
+// FRAGMENT PART (after the vectors).  a_idx: NULL, or M row indices into `a` (< 0: a zero row).
 extern "C" int mmb_transformer_tail(int64_t M, int d, int ff, const float* packed, int n_vec, int wx_o, int wx_1, int wx_2,
                                     int wx_in, const float* a, int64_t a_ld, const float* h, int64_t h_ld, float* out,
-                                    int64_t out_ld, float* qkv, int64_t qkv_ld, float eps1, float eps2, void* stream) {
+                                    int64_t out_ld, float* qkv, int64_t qkv_ld, float eps1, float eps2, const int32_t* a_idx,
+                                    void* stream) {
   MMB_REQUIRE(M > 0, "mmb_transformer_tail: empty shape");
   MMB_REQUIRE(d == 64 || d == 128, "mmb_transformer_tail: model width %d (compiled: 64, 128)", d);
   MMB_REQUIRE(ff > 0 && ff % 64 == 0 && ff <= 1024, "mmb_transformer_tail: FFN width %d (a multiple of 64, <= 1024)", ff);
@@ -198,7 +205,7 @@ extern "C" int mmb_transformer_tail(int64_t M, int d, int ff, const float* packe
   MMB_REQUIRE(wx_o >= 0 && wx_1 >= 0 && wx_2 >= 0 && (!qkv || wx_in >= 0) && wx_o % 4 == 0 && wx_1 % 4 == 0 && wx_2 % 4 == 0 &&
               (!qkv || wx_in % 4 == 0), "mmb_transformer_tail: bad fragment offsets");
   MMB_REQUIRE((M + 127) / 128 < (1ll << 31), "mmb_transformer_tail: too many rows");
-  TailArgs A{packed, n_vec, wx_o, wx_1, wx_2, qkv ? wx_in : 0, M, a, a_ld, h, h_ld, out, out_ld, qkv, qkv_ld, eps1, eps2, ff / 64};
+  TailArgs A{packed, n_vec, wx_o, wx_1, wx_2, qkv ? wx_in : 0, M, a, a_ld, h, h_ld, out, out_ld, qkv, qkv_ld, eps1, eps2, ff / 64, a_idx};
   dim3 grid((unsigned)((M + 127) / 128)), block(256);
   hipStream_t st = as_stream(stream);
   if (d == 64) hipLaunchKernelGGL((transformer_tail_kernel<2>), grid, block, 0, st, A);

@@ -114,7 +114,7 @@ SIGNATURES = {
                                    c_stream],
     "mmb_transformer_tail": [C.c_int64, C.c_int, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
                              C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_float, C.c_float,
-                             c_stream],
+                             c_i32p, c_stream],
     "mmb_layernorm_fwd": [C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_float, c_f32p, C.c_int64, c_f32p,
                           c_stream],
     "mmb_layernorm_bwd": [C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64,

@@ -394,9 +394,10 @@ def pack_transformer_tail(layer, next_layer=None):
                 has_in=Win is not None, wx_in=offs.get("wx_in", 0), **{k: offs[k] for k in ("wx_o", "wx_1", "wx_2")})
 
 
-def transformer_tail(pack, a, h, out=None, want_qkv=True):
-    """-> (out (M,d), qkv (M,3d) | None); see include/mmb_hip.h: mmb_transformer_tail"""
-    M, d = a.shape
+def transformer_tail(pack, a, h, out=None, want_qkv=True, a_idx=None):
+    """-> (out (M,d), qkv (M,3d) | None); see include/mmb_hip.h: mmb_transformer_tail.  a_idx (M,) int32: row r reads
+    a[a_idx[r]] (zeros where negative); a may then have any number of rows and a row pitch > d."""
+    M, d = h.shape
     if out is None:
         out = torch.empty(M, d, dtype=torch.float32, device=a.device)
     qkv = torch.empty(M, 3 * d, dtype=torch.float32, device=a.device) if (want_qkv and pack["has_in"]) else None
@@ -404,8 +405,9 @@ def transformer_tail(pack, a, h, out=None, want_qkv=True):
         macs = d * d + 2 * d * pack["ff"] + (3 * d * d if qkv is not None else 0)
         _m.PROFILE_META = {"M": M, "flops": 2.0 * macs * M, "bytes": 4.0 * M * (3 * d + (3 * d if qkv is not None else 0))}
     call("mmb_transformer_tail", M, d, pack["ff"], f32(pack["packed"]), pack["n_vec"], pack["wx_o"], pack["wx_1"],
-         pack["wx_2"], pack["wx_in"], f32(a, "a"), a.stride(0), f32(h, "h"), h.stride(0), out.data_ptr(), out.stride(0),
-         f32(qkv), qkv.stride(0) if qkv is not None else 0, _fl(pack["eps1"]), _fl(pack["eps2"]), stream())
+         pack["wx_2"], pack["wx_in"], a.data_ptr(), a.stride(0), f32(h, "h"), h.stride(0), out.data_ptr(), out.stride(0),
+         f32(qkv), qkv.stride(0) if qkv is not None else 0, _fl(pack["eps1"]), _fl(pack["eps2"]), i32(a_idx, "a_idx"),
+         stream())
     _m.PROFILE_META = None
     return out, qkv
 

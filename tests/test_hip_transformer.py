@@ -384,6 +384,15 @@ def test_transformer_tail_kernel(d, ff, M, with_next):
         close(qkv, want_qkv, rtol=1e-4, atol=2e-5 * float(want_qkv.abs().max()))
     else:
         assert qkv is None
+    # gathered attention rows: row r reads a_src[idx[r]] out of a wider buffer (pitch 3d), zeros where idx < 0 --
+    # bit-identical to the same call on the materialised rows
+    R = 37
+    a_src = torch.randn(R, 3 * d, device="cuda")
+    idx = torch.randint(-1, R, (M,), dtype=torch.int32, device="cuda")
+    a_rows = torch.where((idx >= 0)[:, None], a_src[:, 2 * d:][idx.clamp(min=0).long()], torch.zeros(M, d, device="cuda"))
+    o1, q1 = fused.transformer_tail(pack, a_rows.contiguous(), h.cuda())
+    o2, q2 = fused.transformer_tail(pack, a_src[:, 2 * d:], h.cuda(), a_idx=idx)
+    assert torch.equal(o1, o2) and (q1 is None or torch.equal(q1, q2))
 
 
 @pytest.mark.parametrize("B,N,H,nh", [(5, 16, 8, 2), (4, 150, 64, 4), (3, 150, 128, 4), (2, 70, 128, 2)])
@@ -410,3 +419,43 @@ def test_attention_uniform_keys(B, N, H, nh, path, monkeypatch):
     close(out.view(B, N, H), want, rtol=1e-5, atol=1e-6 * float(want.abs().max()))
     out2, lse = ops.attention_fwd(qkv.reshape(B * N, 3 * H).cuda(), mi, nh, valid_is_zero=True, want_lse=True)
     close(out2, out, rtol=1e-5, atol=1e-6 * float(want.abs().max()))      # (with lse: the general path)
+
+
+@pytest.mark.parametrize("name", ["tr_tiny", "tr_odd", "S4"])
+def test_transformer_row_compaction_is_bit_identical(golden, name, monkeypatch):
+    """Inference path of MultiModalParticleTransformer: real particles + one padded slot per jet go through the encoder,
+    the representative's heads are copied to the other padded slots (the padded slots' rows are identical by
+    construction, quirk Q4 + the embedder's masking).  Must give the bits of the uncompacted path -- every kernel on
+    it is row-wise -- for ragged masks, a jet without padded slots and a jet without real particles."""
+    import copy
+    from pipeline.configs import ExperimentConfigs
+    from model.multimodal_bridge_matching import MultiModalBridgeMatching
+    from tensorclass import TensorMultiModal
+    g = golden(name)
+    cfg = copy.deepcopy(g.cfg)
+    cfg["data"]["target_path"] = GOLDEN
+    model = MultiModalBridgeMatching(ExperimentConfigs(cfg))
+    model.load_state_dict(g.params, strict=True)
+    model = model.cuda().eval()
+    N = g.t["mask"].shape[1]
+    B = 9
+    gen = torch.Generator().manual_seed(N)
+    n = torch.randint(1, N, (B,), generator=gen)
+    n[0], n[1] = N, 0
+    mask = (torch.arange(N)[None, :] < n[:, None]).long().unsqueeze(-1)
+    if name == "tr_odd":                                        # padded slots anywhere, not only at the end
+        mask = mask[:, torch.randperm(N, generator=gen)]
+    x = torch.randn(B, N, 3, generator=gen)                     # padded slots carry values too (K3)
+    k = torch.randint(0, 8, (B, N, 1), generator=gen)
+    t = torch.rand(B, generator=gen).reshape(B, 1, 1)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MMB_TR_COMPACT", flag)
+        state = TensorMultiModal(t.cuda(), x.cuda(), k.cuda(), mask.cuda())
+        heads = model(state, None)
+        res[flag] = (heads.continuous.clone(), heads.discrete.clone())
+    assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1])
+    # padded slots of a jet all get the same heads; real particles do not
+    hd = res["1"][1]
+    pad = mask[2, :, 0] == 0
+    assert int(pad.sum()) >= 2 and torch.equal(hd[2][pad][0], hd[2][pad][-1])

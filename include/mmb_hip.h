@@ -408,14 +408,18 @@ int mmb_attention_bwd(int B, int N, int H, int nheads, const float* qkv, int64_t
  * decision of (jet b, head h, query q, j-th valid key) is word j & 3 of Philox4x32(seed, offset, index =
  * ((b*nheads + h)*N + q) * ceil(N/4) + (j >> 2)), kept iff u >= drop_p, kept probabilities scaled by 1/(1 - drop_p);
  * the reverse pass regenerates the bits from the same (seed, offset).  lse is that of the UNdropped scores.
- * drop_p = 0 is mmb_attention_fwd / _bwd.  (torch draws its mask from its own generator: same law, other stream.) */
+ * drop_p = 0 is mmb_attention_fwd / _bwd.  (torch draws its mask from its own generator: same law, other stream.)
+ * keep_bits: NULL, or B*nheads*N*ceil(N/32) words: the forward's matrix-core kernels (head width <= 32, N <= 256) leave
+ * the keep bits there, one word per (query, 32-key tile), and the reverse pass reads them instead of regenerating (its
+ * key-major phase needs one Philox call per element otherwise); the other kernels ignore the buffer -- the bits are the
+ * same function of (seed, offset) either way. */
 int mmb_attention_dropout_fwd(int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld, const float* maskf,
                               int valid_is_zero, float* out, int64_t out_ld, float* lse, float drop_p, uint64_t seed,
-                              uint64_t offset, void* stream);
+                              uint64_t offset, uint32_t* keep_bits, void* stream);
 int mmb_attention_dropout_bwd(int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld, const float* maskf,
                               int valid_is_zero, const float* out, int64_t out_ld, const float* dout, int64_t dout_ld,
                               const float* lse, float* dqkv, int64_t dqkv_ld, float drop_p, uint64_t seed,
-                              uint64_t offset, void* stream);
+                              uint64_t offset, const uint32_t* keep_bits, void* stream);
 /* the keep factors of the call above as a dense tensor out (B, nheads, N, N) [b,h,q,n]: 1/(1-drop_p) or 0 at the valid
  * keys n, 0 at the others -- for tests that rebuild the dropped attention with another implementation. */
 int mmb_attention_dropout_mask(int B, int N, int nheads, const float* maskf, int valid_is_zero, float drop_p,

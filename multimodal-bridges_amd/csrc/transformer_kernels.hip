@@ -437,7 +437,7 @@ template <int DH, bool VEC, bool DROP>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DH == 16 ? 8 : 6)))
 attn_fwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int64_t ld,
                      const float* __restrict__ maskf, int valid_is_zero, float scale, float* __restrict__ out,
-                     int64_t out_ld, float* __restrict__ lse, AttnDrop drop, int uniform_ok) {
+                     int64_t out_ld, float* __restrict__ lse, AttnDrop drop, int uniform_ok, uint32_t* __restrict__ keep_bits) {
   constexpr int P = DH + 4, HD = DH / 2, DT = (DH + 31) / 32;
   extern __shared__ float sm[];
   int b, h;
@@ -500,11 +500,17 @@ attn_fwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv
       l = fmaf(l, alpha, ps);
       m = mn;
       if constexpr (DROP) {                      // registers 4g..4g+3 of a lane hold four consecutive keys of its query
+        uint32_t word = 0;                         // bit c = key kt + c of this query
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const uint32_t kb = attn_keep4(drop, (int64_t)b * nh + h, N, q < N ? q : 0, (kt + 8 * g + 4 * par) >> 2);
+          word |= kb << (8 * g + 4 * par);
 #pragma unroll
           for (int i = 0; i < 4; ++i) s[4 * g + i] = ((kb >> i) & 1u) ? s[4 * g + i] * drop.inv_keep : 0.0f;
+        }
+        if (keep_bits != nullptr) {                // for the reverse pass: one word per (query, 32-key tile)
+          word |= (uint32_t)__shfl_xor((int)word, 32, 64);
+          if (par == 0 && q < N) keep_bits[(((int64_t)b * nh + h) * N + q) * ((N + 31) >> 5) + (kt >> 5)] = word;
         }
       }
 #pragma unroll
@@ -528,7 +534,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DH == 
 attn_bwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv, int64_t ld,
                      const float* __restrict__ maskf, int valid_is_zero, float scale, const float* __restrict__ out,
                      int64_t out_ld, const float* __restrict__ dout, int64_t dout_ld, const float* __restrict__ lse,
-                     float* __restrict__ dqkv, int64_t dld, AttnDrop drop) {
+                     float* __restrict__ dqkv, int64_t dld, AttnDrop drop, const uint32_t* __restrict__ keep_bits) {
   constexpr int P = DH + 4, HD = DH / 2, DT = (DH + 31) / 32;
   extern __shared__ float sm[];
   int b, h;
@@ -587,11 +593,17 @@ attn_bwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv
         dp = MMB_MFMA_F32(vr[i], gr[i], dp);
       }
       if constexpr (DROP) {
+        if (keep_bits != nullptr) {                // the forward's words (bit c = key kt + c)
+          const uint32_t word = keep_bits[(((int64_t)b * nh + h) * N + (q < N ? q : 0)) * ((N + 31) >> 5) + (kt >> 5)];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const uint32_t kb = attn_keep4(drop, (int64_t)b * nh + h, N, q < N ? q : 0, (kt + 8 * g + 4 * par) >> 2);
+          for (int r = 0; r < 16; ++r) dp[r] = ((word >> crow(r, par)) & 1u) ? dp[r] * drop.inv_keep : 0.0f;
+        } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) dp[4 * g + i] = ((kb >> i) & 1u) ? dp[4 * g + i] * drop.inv_keep : 0.0f;
+          for (int g = 0; g < 4; ++g) {
+            const uint32_t kb = attn_keep4(drop, (int64_t)b * nh + h, N, q < N ? q : 0, (kt + 8 * g + 4 * par) >> 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dp[4 * g + i] = ((kb >> i) & 1u) ? dp[4 * g + i] * drop.inv_keep : 0.0f;
+          }
         }
       }
 #pragma unroll
@@ -649,7 +661,13 @@ attn_bwd_mfma_kernel(int N, int H, int nh, int dh, const float* __restrict__ qkv
           const int qq = qt + crow(r, par);
           const float p = qq < N ? __builtin_amdgcn_exp2f(s[r] - Ls[qq]) : 0.0f;
           float c = 1.0f;
-          if constexpr (DROP) c = attn_keep1(drop, (int64_t)b * nh + h, N, qq < N ? qq : 0, kt + col);   // (lane = key)
+          if constexpr (DROP) {                                                  // (lane = key kt + col)
+            if (keep_bits != nullptr)          // one broadcast word per query instead of one Philox call per element
+              c = ((keep_bits[(((int64_t)b * nh + h) * N + (qq < N ? qq : 0)) * ((N + 31) >> 5) + (kt >> 5)] >> col) & 1u)
+                      ? drop.inv_keep : 0.0f;
+            else
+              c = attn_keep1(drop, (int64_t)b * nh + h, N, qq < N ? qq : 0, kt + col);
+          }
           dp[r] = p * (dp[r] * c - Ds[qq]);
           s[r] = p * c;
         }
@@ -957,7 +975,7 @@ static int attn_check(const char* fn, int B, int N, int H, int nheads, int64_t l
 
 static int attention_fwd_impl(const char* fn, int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld,
                               const float* maskf, int valid_is_zero, float* out, int64_t out_ld, float* lse,
-                              const AttnDrop& drop, void* stream) {
+                              const AttnDrop& drop, uint32_t* keep_bits, void* stream) {
   MMB_REQUIRE(qkv && maskf && out, "%s: NULL argument", fn);
   const int dh = nheads > 0 ? H / nheads : 0, dhp = pad_dh(dh);
   const bool mfma = N > 0 && dh > 0 && attn_use_mfma(N, dh, false);
@@ -973,7 +991,7 @@ static int attention_fwd_impl(const char* fn, int B, int N, int H, int nheads, c
     const bool vec = dh % 4 == 0 && qkv_ld % 4 == 0 && out_ld % 4 == 0 && aligned16(qkv) && aligned16(out);
 #define MMB_FWD_MFMA(DHV, VECV, DROPV)                                                                                \
   hipLaunchKernelGGL((attn_fwd_mfma_kernel<DHV, VECV, DROPV>), grid, block, lds, st, N, H, nheads, dh, qkv, qkv_ld,    \
-                     maskf, valid_is_zero, scale, out, out_ld, lse, drop, uniform_ok)
+                     maskf, valid_is_zero, scale, out, out_ld, lse, drop, uniform_ok, keep_bits)
 #define MMB_FWD_MFMA2(DHV, VECV) do { if (drop.p > 0.0f) MMB_FWD_MFMA(DHV, VECV, true); else MMB_FWD_MFMA(DHV, VECV, false); } while (0)
     if (dh <= 16) { if (vec) MMB_FWD_MFMA2(16, true); else MMB_FWD_MFMA2(16, false); }
     else { if (vec) MMB_FWD_MFMA2(32, true); else MMB_FWD_MFMA2(32, false); }
@@ -990,16 +1008,16 @@ extern "C" int mmb_attention_fwd(int B, int N, int H, int nheads, const float* q
                                  const float* maskf, int valid_is_zero, float* out, int64_t out_ld, float* lse,
                                  void* stream) {
   return attention_fwd_impl("mmb_attention_fwd", B, N, H, nheads, qkv, qkv_ld, maskf, valid_is_zero, out, out_ld, lse,
-                            AttnDrop{0.0f, 1.0f, 0, 0}, stream);
+                            AttnDrop{0.0f, 1.0f, 0, 0}, nullptr, stream);
 }
 
 extern "C" int mmb_attention_dropout_fwd(int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld,
                                          const float* maskf, int valid_is_zero, float* out, int64_t out_ld, float* lse,
-                                         float drop_p, uint64_t seed, uint64_t offset, void* stream) {
+                                         float drop_p, uint64_t seed, uint64_t offset, uint32_t* keep_bits, void* stream) {
   AttnDrop d;
   if (int rc = attn_drop_args("mmb_attention_dropout_fwd", drop_p, seed, offset, d)) return rc;
   return attention_fwd_impl("mmb_attention_dropout_fwd", B, N, H, nheads, qkv, qkv_ld, maskf, valid_is_zero, out, out_ld,
-                            lse, d, stream);
+                            lse, d, keep_bits, stream);
 }
 
 extern "C" int mmb_attention_dropout_mask(int B, int N, int nheads, const float* maskf, int valid_is_zero, float drop_p,
@@ -1016,7 +1034,7 @@ extern "C" int mmb_attention_dropout_mask(int B, int N, int nheads, const float*
 static int attention_bwd_impl(const char* fn, int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld,
                               const float* maskf, int valid_is_zero, const float* out, int64_t out_ld,
                               const float* dout, int64_t dout_ld, const float* lse, float* dqkv, int64_t dqkv_ld,
-                              const AttnDrop& drop, void* stream) {
+                              const AttnDrop& drop, const uint32_t* keep_bits, void* stream) {
   MMB_REQUIRE(qkv && maskf && out && dout && lse && dqkv, "%s: NULL argument", fn);
   const int dh = nheads > 0 ? H / nheads : 0, dhp = pad_dh(dh);
   const bool mfma = N > 0 && dh > 0 && attn_use_mfma(N, dh, true);
@@ -1032,7 +1050,7 @@ static int attention_bwd_impl(const char* fn, int B, int N, int H, int nheads, c
                      aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv);
 #define MMB_BWD_MFMA(DHV, VECV, DROPV)                                                                                \
   hipLaunchKernelGGL((attn_bwd_mfma_kernel<DHV, VECV, DROPV>), grid, block, lds, st, N, H, nheads, dh, qkv, qkv_ld,    \
-                     maskf, valid_is_zero, scale, out, out_ld, dout, dout_ld, lse, dqkv, dqkv_ld, drop)
+                     maskf, valid_is_zero, scale, out, out_ld, dout, dout_ld, lse, dqkv, dqkv_ld, drop, keep_bits)
 #define MMB_BWD_MFMA2(DHV, VECV) do { if (drop.p > 0.0f) MMB_BWD_MFMA(DHV, VECV, true); else MMB_BWD_MFMA(DHV, VECV, false); } while (0)
     if (dh <= 16) { if (vec) MMB_BWD_MFMA2(16, true); else MMB_BWD_MFMA2(16, false); }
     else { if (vec) MMB_BWD_MFMA2(32, true); else MMB_BWD_MFMA2(32, false); }
@@ -1050,17 +1068,18 @@ extern "C" int mmb_attention_bwd(int B, int N, int H, int nheads, const float* q
                                  const float* dout, int64_t dout_ld, const float* lse, float* dqkv, int64_t dqkv_ld,
                                  void* stream) {
   return attention_bwd_impl("mmb_attention_bwd", B, N, H, nheads, qkv, qkv_ld, maskf, valid_is_zero, out, out_ld, dout,
-                            dout_ld, lse, dqkv, dqkv_ld, AttnDrop{0.0f, 1.0f, 0, 0}, stream);
+                            dout_ld, lse, dqkv, dqkv_ld, AttnDrop{0.0f, 1.0f, 0, 0}, nullptr, stream);
 }
 
 extern "C" int mmb_attention_dropout_bwd(int B, int N, int H, int nheads, const float* qkv, int64_t qkv_ld,
                                          const float* maskf, int valid_is_zero, const float* out, int64_t out_ld,
                                          const float* dout, int64_t dout_ld, const float* lse, float* dqkv,
-                                         int64_t dqkv_ld, float drop_p, uint64_t seed, uint64_t offset, void* stream) {
+                                         int64_t dqkv_ld, float drop_p, uint64_t seed, uint64_t offset,
+                                         const uint32_t* keep_bits, void* stream) {
   AttnDrop d;
   if (int rc = attn_drop_args("mmb_attention_dropout_bwd", drop_p, seed, offset, d)) return rc;
   return attention_bwd_impl("mmb_attention_dropout_bwd", B, N, H, nheads, qkv, qkv_ld, maskf, valid_is_zero, out, out_ld,
-                            dout, dout_ld, lse, dqkv, dqkv_ld, d, stream);
+                            dout, dout_ld, lse, dqkv, dqkv_ld, d, keep_bits, stream);
 }
 
 extern "C" int mmb_layernorm_fwd(int64_t M, int D, const float* x, int64_t x_ld, const float* gamma, const float* beta,

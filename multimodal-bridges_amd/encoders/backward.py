@@ -164,7 +164,14 @@ def _relu_gates(tape):
             ref = e[8] if e[4] == "gelu" else e[9]          # GELU' needs the pre-activation, the others y1's sign / value
             key = k(e[9])
             if ref is not None and uses.get(key, 0) == 1 and row_uses.get(key, 0) == 1:
-                gates[key] = (e[4], ref)
+                gates[key] = (e[4], ref, 1.0)
+        # relu followed by a plain dropout (the transformer's FFN): y2 = keep * relu(z) / (1 - p) is positive exactly where
+        # the gradient passes, so dZ = (consumer's input gradient) * [y2 > 0] / (1 - p) -- no Philox, no mmb_act_bwd pass
+        elif e[0] in ("linear", "plinear") and e[4] == "relu" and e[5] is None and e[6] is None and e[7] is None \
+                and e[9] is None and e[10] is not None and e[11] > 0.0 and GradStore._owns_storage(e[10]):
+            key = k(e[10])
+            if uses.get(key, 0) == 1 and row_uses.get(key, 0) == 1:
+                gates[key] = ("relu", e[10], 1.0 / (1.0 - e[11]))
     return gates
 
 
@@ -279,6 +286,8 @@ def _linear_bwd(e, store, produced, mi, seed, arena, touched):
         dZ = gY1                        # identity first stage, no gradient through the second: nothing to compute
     elif y1 is not None and GradStore._key(y1) in store.gated:
         dZ = gY1                        # its consumer's GEMM already applied relu' (mmb_linear_cat_gate)
+    elif y1 is None and y2 is not None and GradStore._key(y2) in store.gated:
+        dZ = gY2                        # ... and, for relu + dropout, the keep factor with it
     else:
         dZ = ops.act_bwd(M, Nout, gY1, gY2, y1, y2, res2, pre, act, post, p, seed, off)
     if res2 is not None and gY2 is not None and GradStore._key(res2) in produced:
@@ -311,8 +320,9 @@ def _linear_bwd(e, store, produced, mi, seed, arena, touched):
             res = None if fresh else gx
             Wseg = WT[koff:koff + Ks]
             if kind == SEG_ROW and fresh and GradStore._key(t) in store.relu_gates:
-                g_act, g_ref = store.relu_gates[GradStore._key(t)]
-                ops.linear_cat_gate([(dZ, SEG_ROW)], Wseg, N, g_ref, gx, act=g_act)    # dZ of the activated layer
+                g_act, g_ref, g_scale = store.relu_gates[GradStore._key(t)]
+                Wg = Wseg if g_scale == 1.0 else (Wseg * g_scale).contiguous()         # (a d x ff matrix: one tiny launch)
+                ops.linear_cat_gate([(dZ, SEG_ROW)], Wg, N, g_ref, gx, act=g_act)      # dZ of the activated layer
                 store.gated.add(GradStore._key(t))
             elif kind == SEG_ROW:
                 ops.linear_cat([(dZ, SEG_ROW)], Wseg, None, N, residual=res, out=gx)
@@ -325,9 +335,11 @@ def _linear_bwd(e, store, produced, mi, seed, arena, touched):
 def _attn_bwd(e, store, mi, seed=0):
     _, qkv, a, lse, nheads = e[:5]
     p, off = (e[5], e[6]) if len(e) > 5 else (0.0, 0)
+    bits = e[7] if len(e) > 7 else None
     g = store.get(a)
     if g is not None:
-        store.add(qkv, ops.attention_bwd(qkv, mi, nheads, a, g, lse, valid_is_zero=True, drop_p=p, seed=seed, offset=off))
+        store.add(qkv, ops.attention_bwd(qkv, mi, nheads, a, g, lse, valid_is_zero=True, drop_p=p, seed=seed, offset=off,
+                                         keep_bits=bits))
 
 
 def _ln_bwd(e, store, produced, arena):

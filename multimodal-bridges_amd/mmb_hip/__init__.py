@@ -106,10 +106,10 @@ SIGNATURES = {
     "mmb_attention_bwd": [C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, C.c_int, c_f32p, C.c_int64,
                           c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_stream],
     "mmb_attention_dropout_fwd": [C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, C.c_int, c_f32p,
-                                  C.c_int64, c_f32p, C.c_float, C.c_uint64, C.c_uint64, c_stream],
+                                  C.c_int64, c_f32p, C.c_float, C.c_uint64, C.c_uint64, c_i32p, c_stream],
     "mmb_attention_dropout_bwd": [C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, C.c_int, c_f32p,
                                   C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_uint64,
-                                  C.c_uint64, c_stream],
+                                  C.c_uint64, c_i32p, c_stream],
     "mmb_attention_dropout_mask": [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, C.c_float, C.c_uint64, C.c_uint64, c_f32p,
                                    c_stream],
     "mmb_transformer_tail": [C.c_int64, C.c_int, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,

@@ -587,7 +587,8 @@ def grad_weight_smallk(X, dZ, dW, db=None):
 # ------------------------------------------------------------------------ transformer set encoder
 def attention_fwd(qkv, mi, nheads, valid_is_zero=True, want_lse=False, drop_p=0.0, seed=0, offset=0):
     """qkv (B*N, 3H) [q|k|v] -> out (B*N, H) (+ lse (B, nheads, N) for the backward).  drop_p > 0: dropout on the
-    attention probabilities (training mode of nn.MultiheadAttention), Philox keyed by (seed, offset)."""
+    attention probabilities (training mode of nn.MultiheadAttention), Philox keyed by (seed, offset); with want_lse
+    the result is (out, lse, keep_bits): hand keep_bits to attention_bwd."""
     B, N = mi.B, mi.N
     H = qkv.shape[1] // 3
     if qkv.dim() != 2 or qkv.shape[0] != B * N or qkv.shape[1] != 3 * H or qkv.stride(1) != 1:
@@ -596,15 +597,18 @@ def attention_fwd(qkv, mi, nheads, valid_is_zero=True, want_lse=False, drop_p=0.
     out = torch.empty(B * N, H, dtype=torch.float32, device=qkv.device)
     lse = torch.empty(B, nheads, N, dtype=torch.float32, device=qkv.device) if want_lse else None
     if drop_p > 0.0:
+        bits = torch.empty(B * nheads * N * ((N + 31) // 32), dtype=torch.int32, device=qkv.device) if want_lse else None
         call("mmb_attention_dropout_fwd", B, N, H, nheads, qkv.data_ptr(), qkv.stride(0), f32(mi.maskf),
-             int(bool(valid_is_zero)), f32(out), out.stride(0), f32(lse), _fl(drop_p), seed, offset, stream())
+             int(bool(valid_is_zero)), f32(out), out.stride(0), f32(lse), _fl(drop_p), seed, offset, i32(bits), stream())
+        if want_lse:
+            return out, lse, bits
     else:
         call("mmb_attention_fwd", B, N, H, nheads, qkv.data_ptr(), qkv.stride(0), f32(mi.maskf),
              int(bool(valid_is_zero)), f32(out), out.stride(0), f32(lse), stream())
     return (out, lse) if want_lse else out
 
 
-def attention_bwd(qkv, mi, nheads, out, dout, lse, valid_is_zero=True, drop_p=0.0, seed=0, offset=0):
+def attention_bwd(qkv, mi, nheads, out, dout, lse, valid_is_zero=True, drop_p=0.0, seed=0, offset=0, keep_bits=None):
     B, N = mi.B, mi.N
     H = qkv.shape[1] // 3
     if dout.stride(1) != 1 or out.stride(1) != 1:
@@ -613,7 +617,7 @@ def attention_bwd(qkv, mi, nheads, out, dout, lse, valid_is_zero=True, drop_p=0.
     if drop_p > 0.0:
         call("mmb_attention_dropout_bwd", B, N, H, nheads, qkv.data_ptr(), qkv.stride(0), f32(mi.maskf),
              int(bool(valid_is_zero)), out.data_ptr(), out.stride(0), dout.data_ptr(), dout.stride(0), f32(lse), f32(dqkv),
-             dqkv.stride(0), _fl(drop_p), seed, offset, stream())
+             dqkv.stride(0), _fl(drop_p), seed, offset, i32(keep_bits), stream())
     else:
         call("mmb_attention_bwd", B, N, H, nheads, qkv.data_ptr(), qkv.stride(0), f32(mi.maskf),
              int(bool(valid_is_zero)), out.data_ptr(), out.stride(0), dout.data_ptr(), dout.stride(0), f32(lse), f32(dqkv),

@@ -174,7 +174,7 @@ def test_attention_dropout_forward_backward(B, N, H, nh, path, monkeypatch):
     q64 = qkv.double().requires_grad_(True)
     want = ref_attention(q64, mask, nh, True, keep=keep.double())
     (want * dout.double()).sum().backward()
-    out, lse = ops.attention_fwd(qd, mi, nh, valid_is_zero=True, want_lse=True, drop_p=p, seed=seed, offset=off)
+    out, lse, bits = ops.attention_fwd(qd, mi, nh, valid_is_zero=True, want_lse=True, drop_p=p, seed=seed, offset=off)
     out0, lse0 = ops.attention_fwd(qd, mi, nh, valid_is_zero=True, want_lse=True)
     scale = float(want.detach().abs().max())
     close(out.view(B, N, H), want, rtol=1e-4, atol=2e-5 * scale)
@@ -185,6 +185,10 @@ def test_attention_dropout_forward_backward(B, N, H, nh, path, monkeypatch):
                            offset=off)
     gs = float(q64.grad.abs().max())
     close(dq.view(B, N, 3 * H), q64.grad, rtol=1e-4, atol=2e-5 * gs)
+    # the reverse pass reading the forward's stored keep bits (matrix-core kernels) instead of regenerating them
+    dq2 = ops.attention_bwd(qd, mi, nh, out, dout.reshape(B * N, H).cuda(), lse, valid_is_zero=True, drop_p=p, seed=seed,
+                            offset=off, keep_bits=bits)
+    assert torch.equal(dq2, dq)
 
 
 def _dropout_factors(M, Nout, p, seed, off):

@@ -119,7 +119,10 @@ __device__ __forceinline__ void layer_norm(f32x16 (&x)[DT], const float* gamma, 
 constexpr int TAIL_MAX_VEC = 6 * 128 + 1024 + 3 * 128;      // d <= 128, ff <= 1024
 
 template <int DT>
-__global__ void __launch_bounds__(256, DT == 4 ? 1 : 2)   // d = 128: 385 registers, one workgroup per CU (256 + spills measured slower)
+#ifndef MMB_TAIL_WG128
+#define MMB_TAIL_WG128 2       // workgroups per CU of the d = 128 variant: 2 = 256 registers + 92 B/lane of spills, 1 = 385
+#endif                         // registers, no spills; measured 299 / 91 us (2) against 312 / 97 us (1) at 153.6 k / 50 k rows
+__global__ void __launch_bounds__(256, DT == 4 ? MMB_TAIL_WG128 : 2)
 transformer_tail_kernel(TailArgs A) {
   typedef TailVec<DT> V;
   constexpr int D = 32 * DT, RD = 4;

@@ -543,7 +543,12 @@ int mmb_fused_uni_train_backward(int variant, int B, int N, const float* packed_
  * injected Poisson counts or NULL for the Philox jump sampler (seed, offset).
  * em != 0 replaces the Euler step by Euler-Maruyama (solvers.py:27-33, Q5-repaired diffusion
  * sigma_t = em_sigma*sqrt(t(1-t)), NO sqrt(dt)): x += dt v + sigma_t dW with dW from delta_w
- * (steps,B,N,3) or, when NULL, Philox + Box-Muller. */
+ * (steps,B,N,3) or, when NULL, Philox + Box-Muller.
+ * Padded slots: a 32-particle tile without a real particle does no per-particle work -- the kernel puts the real
+ * particles of a jet first (whatever slots the mask marks; noise.py:36-37 permutes every mask) and the padded slots of
+ * idle tiles take drift and logits from one padded slot of a working tile: the same row, so they move exactly as before.
+ * jet_order (B) | NULL: a permutation of the jets; workgroup i starts with jet jet_order[i].  A jet costs what its
+ * working tiles cost, so longest-first (mmb_jet_schedule) keeps the last workgroups short; results do not depend on it. */
 int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, const int32_t* desc,
                             int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip,
                             int off_cw, int off_cb, int off_table,
@@ -552,7 +557,12 @@ int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, cons
                             const float* ctab_steps, int n_ctab, float dt,
                             int thermo_kind, float gamma, const float* delta_n,
                             uint64_t seed, uint64_t offset,
-                            int em, float em_sigma, const float* delta_w, void* stream);
+                            int em, float em_sigma, const float* delta_w, const int32_t* jet_order, void* stream);
+
+/* Launch order for the generation loops: order (B) = the jets sorted by particle count (counts, as passed to the
+ * generation call), descending.  No counterpart in the reference (its loop runs whole batches through dense layers);
+ * one workgroup, a counting sort. */
+int mmb_jet_schedule(int B, const int32_t* counts, int32_t* order, void* stream);
 
 /* UniModalEPiC (discrete-only model): MultiModalBridgeMatching.forward with
  * encoders/multimodal_epic.py:44-64 (+ embedder.py:74-80, epic.py:71-98) for one jet per workgroup.
@@ -574,7 +584,7 @@ int mmb_fused_uni_generate(int variant, int B, int N, const float* packed, const
                            int steps, const float* times, const float* temb_steps,
                            const float* ctab_steps, int n_ctab, float dt,
                            int thermo_kind, float gamma, const float* delta_n,
-                           uint64_t seed, uint64_t offset, void* stream);
+                           uint64_t seed, uint64_t offset, const int32_t* jet_order, void* stream);
 
 /* ---------------------------------------------------------------- toy config (BASELINE configs[0]) */
 /* Input rows of the toy MLP: rows[p,:] = [t(jet of p), x[p,0:Dc], table[k[p],0:E]]  (P, 1+Dc+E) --

@@ -69,7 +69,14 @@ struct FCtx {
   float m;                 // this lane's particle mask
   int tid, lane, wave, half, lane16;
   const float* ctab;       // (n_c_layers,128) time vectors W_t temb of the CURRENT grid point (CT kernels)
+  bool active;             // wave-uniform: this wave's tile takes part in the per-particle work (see TilePlan)
 };
+
+// An idle tile contributes exact zeros to the pooled sums
+__device__ __forceinline__ void zero_partials(float* partial, int wave, int lane) {
+  partial[wave * 128 + lane] = 0.0f;
+  partial[wave * 128 + 64 + lane] = 0.0f;
+}
 
 // Issue priority of this wave against the other jet's wave on the same SIMD (arbitration is by priority, then age).
 // The per-jet chain is a string of short dependent steps between barriers: when the partner sits in a GEMM -- MFMAs
@@ -188,7 +195,8 @@ struct Epic {
     if constexpr (!CT) MVT::template prefetch<false>(wt, c.R, fld<F_WT>(dv.d[2]), 0, tid);
     ++ci;
     FE_PROF(L, PF_X1);
-    pool_partials<HT>(x, c.m, L.partial, wave, lane);
+    if (c.active) pool_partials<HT>(x, c.m, L.partial, wave, lane);
+    else zero_partials(L.partial, wave, lane);
     FE_PROF(L, PF_X2);
     typename MVB::Pre wb;
     typename MVC::Pre wc;
@@ -252,6 +260,7 @@ struct Epic {
 #endif
     FE_PROF(L, PF_DVEC);
     prio_gemm();
+    if (c.active) {
     f32x16 lh[HT];
     acc_init<HT>(lh, c.m, L.cvec, L.dvec, half);
     mma_r<HT, HT, RD, true>(lh, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, c.R, fld<F_WX>(dv.d[2]), fld<F_WX>(dv.d[3]), c.lane16, ring);
@@ -290,6 +299,7 @@ struct Epic {
         ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; x[t][r] += sk[r]; });
       } });
     if constexpr (TR::on) tr.template tiles<HT>(x, half);
+    }
     FE_PROF(L, PF_EPI);
   }
 
@@ -323,9 +333,11 @@ struct Epic {
     }
     sync_pin();
     prio_gemm();
+    if (c.active) {
     acc_init<OTO>(out, c.m, L.cvec, L.dvec, half);
     mma_r<HT, OTO, RD, PFN>(out, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, c.R, fld<F_WX>(dv.d[0]), next_wx, c.lane16, ring);
     if constexpr (TR::on && OW == 32 * OTO) tr.template tiles<OTO>(out, half);
+    }
     FE_PROF(L, PF_OUT);
   }
 
@@ -358,6 +370,7 @@ struct Epic {
     if (wave == 2) stage_commit(st, L.bvec, H, lane);
     sync_pin();
     prio_gemm();
+    if (c.active) {
     f32x16 h[HT];
     acc_init<HT>(h, c.m, L.cvec, L.dvec, half);
     mma_r<KIN, HT, RD, true>(h, xin, c.R, fld<F_WX>(dv.d[0]), fld<F_WX>(dv.d[1]), c.lane16, ring);
@@ -369,11 +382,13 @@ struct Epic {
     if constexpr (TR::on) tr.template tiles<HT>(x, half);
     act_tiles<HT, MMB_ACT_GELU>(x);
     if constexpr (TR::on) tr.template tiles<HT>(x, half);
+    }
     FE_PROF(L, PF_PROJ_MMA);
     prio_chain();
     typename MVQ0::Pre wq0;
     if constexpr (CARRY) MVQ0::prefetch(wq0, c.R, fld<F_WT>(dv.d[2]), fld<F_B>(dv.d[2]), tid);
-    pool_partials<HT>(x, c.m, L.partial, wave, lane);
+    if (c.active) pool_partials<HT>(x, c.m, L.partial, wave, lane);
+    else zero_partials(L.partial, wave, lane);
     typename MV<H, G>::Pre wq2;
     if constexpr (CARRY) MV<H, G>::prefetch(wq2, c.R, fld<F_WT>(dv.d[3]), fld<F_B>(dv.d[3]), tid);
     sync_pin();
@@ -411,6 +426,8 @@ struct GenArgs {
   float em_sigma;
   const float* delta_w;      // (steps,B,N,DC) injected Wiener increments or NULL -> Philox/Box-Muller
   int stagger;               // core-clock cycles the second workgroup of a CU waits before its first forward (0: none)
+  int tiles;                 // bit 0: tiles of padded slots only stay idle (TilePlan); bit 1: tiles steered to SIMDs
+  const int32_t* jet_order;  // (B) a permutation of the jets, workgroup i starts with jet_order[i]; NULL: 0, 1, 2, ...
 };
 
 // Two jets share a CU and run the SAME program: started together they stay in lock-step -- both in their GEMMs
@@ -429,6 +446,80 @@ __device__ __forceinline__ void stagger_start(int cycles, int tid, int* flag) {
   __syncthreads();
 }
 
+
+// Which of a jet's 32-particle tiles do per-particle work in the generation loops.  A padded slot never enters a pooled
+// sum (the mask) and its own inputs are zero (embedder.py:74-80 + apply_mask): every padded slot of a jet carries the
+// same row through the encoder.  The solvers move padded slots all the same (K3), so that row is still needed -- once:
+// a tile with nothing but padded slots stays idle and takes drift and logits of every grid point from one
+// representative padded slot of an active tile (rows of an MFMA product do not depend on their position: bit-identical).
+// AOJ multiplicities (48 particles on average, 82 % of the jets below 65) leave two of four tiles idle on average.
+struct TilePlan {
+  bool active;       // wave-uniform: this wave's tile computes
+  bool idle_any;     // workgroup-uniform: some tile with valid slots is idle, the representative publishes the heads
+  bool rep;          // this lane holds the representative padded slot (lane half 0)
+};
+__device__ __forceinline__ TilePlan plan_tiles(bool on, float m, bool valid, int wave, int lane, int* red) {
+  const unsigned long long pad_b = __ballot(valid && m == 0.0f);
+  const bool real = __ballot(m != 0.0f) != 0;
+  __syncthreads();                                       // the readers of red's last use
+  if (lane == 0) red[wave] = (real ? 1 : 0) | (pad_b != 0 ? 2 : 0);
+  __syncthreads();
+  int act = 0, pad = 0;
+  for (int w = 0; w < FE_WAVES; ++w) { const int f = red[w]; act |= (f & 1) << w; pad |= ((f >> 1) & 1) << w; }
+  int rep = -1;
+  if (act & pad) rep = __ffs(act & pad) - 1;
+  else if (pad) { rep = __ffs(pad) - 1; act |= 1 << rep; }     // no padded slot next to a real one: one more tile works
+  if (!on) { act = (1 << FE_WAVES) - 1; rep = -1; }
+  TilePlan t;
+  t.active = __builtin_amdgcn_readfirstlane((act >> wave) & 1) != 0;
+  t.idle_any = __builtin_amdgcn_readfirstlane(pad & ~act) != 0;
+  t.rep = wave == rep && lane == (int)__ffsll((long long)pad_b) - 1;
+  return t;
+}
+
+// Slot order of a jet inside the generation kernels: real particles first (stable), padded slots behind them, so that a
+// short jet fills whole tiles and leaves whole tiles idle whatever slots its mask marks -- the reference's sources permute
+// every mask (distributions/noise.py:36-37).  EPiC is permutation-equivariant: a particle's row does not depend on its
+// slot, only the pooled sums move in their last bits with the order of summation (not at all for a mask that already is
+// a prefix).  Injected noise and the Philox keys stay indexed by the true slot.  Returns the true slot behind `slot`.
+__device__ __forceinline__ int jet_order(bool on, const float* maskf, int N, int slot, int wave, int lane, int* red,
+                                         short* order) {
+  if (!on) return slot;
+  const bool valid = slot < N;
+  const float m = valid ? maskf[slot] : 0.0f;
+  const unsigned real_b = (unsigned)__ballot(m != 0.0f), pad_b = (unsigned)__ballot(valid && m == 0.0f);   // lanes 0..31
+  __syncthreads();                                       // the readers of red's last use
+  if (lane == 0) red[wave] = __popc(real_b) | (__popc(pad_b) << 8);
+  __syncthreads();
+  int n_real = 0, real_before = 0, pad_before = 0;
+  for (int w = 0; w < FE_WAVES; ++w) {
+    const int f = red[w];
+    n_real += f & 255;
+    if (w < wave) { real_before += f & 255; pad_before += f >> 8; }
+  }
+  const unsigned below = (1u << (lane & 31)) - 1u;
+  const int pos = m != 0.0f ? real_before + __popc(real_b & below) : n_real + pad_before + __popc(pad_b & below);
+  if (valid && lane < 32) order[pos] = (short)slot;
+  __syncthreads();
+  return valid ? order[slot] : slot;
+}
+
+// Two jets share a CU, one wave of each on every SIMD, and most jets leave tiles idle: which SIMDs the working tiles sit
+// on decides whether the two jets' GEMMs meet on the same matrix pipes.  Tile t goes to SIMD t in the workgroup that
+// holds the first wave slot and to SIMD 3 - t in the other one (measured with two working tiles per jet: 62 ms -> 56 ms
+// for the S3 loop).  Returns the tile of this wave; the hardware wave order when the four waves do not sit on four SIMDs.
+__device__ __forceinline__ int steer_wave(bool on, int hw_wave, int lane, int* red) {
+  if (FE_WAVES != 4 || !on) return hw_wave;
+  const unsigned id = __builtin_amdgcn_s_getreg((5 << 11) | 4);      // HW_REG_HW_ID[5:0]: wave slot [3:0], SIMD [5:4]
+  if (lane == 0) red[hw_wave] = (int)id;
+  __syncthreads();
+  int seen = 0;
+  for (int w = 0; w < 4; ++w) seen |= 1 << ((red[w] >> 4) & 3);
+  const int flip = red[0] & 1, simd = (int)(id >> 4) & 3;
+  const int wave = seen == 0xF ? (flip ? 3 - simd : simd) : hw_wave;
+  __syncthreads();
+  return __builtin_amdgcn_readfirstlane(wave);
+}
 
 struct FusedArgs {
   const float* ctab;       // generation: (n_c_layers,128) time vectors W_t temb of the CURRENT grid point, or NULL
@@ -503,6 +594,7 @@ __device__ __forceinline__ void head(f32x16& o, InFn&& in, FCtx& c, int i0, int 
   if (wave == 2) stage_commit(st, L.bvec, 32, lane);
   sync_pin();
   prio_gemm();
+  if (c.active) {
   f32x16 h[HBT];
   acc_init<HBT>(h, c.m, L.cvec, L.dvec, half);
   mma_r<HFT, HBT, RD, true>(h, in, c.R, fld<F_WX>(dv.d[0]), fld<F_WX>(dv.d[1]), c.lane16, ring);
@@ -513,6 +605,7 @@ __device__ __forceinline__ void head(f32x16& o, InFn&& in, FCtx& c, int i0, int 
   acc_init<1>(oo, 0.0f, nullptr, L.bvec, half);
   mma_r<HBT, 1, RD, true>(oo, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, c.R, fld<F_WX>(dv.d[1]), next_wx, c.lane16, ring);
   o = oo[0];
+  }
 }
 
 // Whole MultiModalEPiC forward for this jet.  which: 0 continuous head, 1 discrete head, 2 both.
@@ -524,12 +617,12 @@ __device__ __forceinline__ void head(f32x16& o, InFn&& in, FCtx& c, int i0, int 
 template <class DM, bool CT, class TR>
 __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* S, const float (&xp)[4], int kp, float m,
                                             int which, f32x16& hc, f32x16& hd, int tid,
-                                            WRing<ring_depth_multi<DM>()>& ring, TR& tr) {
+                                            WRing<ring_depth_multi<DM>()>& ring, TR& tr, bool active = true) {
   constexpr int HBT = DM::HBT, HFT = DM::HFT, RD = ring_depth_multi<DM>();
   typedef Epic<HBT, DM::ET, DM::GB, RD, CT> EB;
   typedef Epic<HFT, DM::ET, DM::GF, RD, CT> EF;
   const int lane = tid & 63, half = lane >> 5;
-  FCtx c{A.P, weight_rsrc(A.P), L, m, tid, lane, tid >> 6, half, lane * 16, A.ctab};
+  FCtx c{A.P, weight_rsrc(A.P), L, m, tid, lane, tid >> 6, half, lane * 16, A.ctab, active};
   int li = 0, ci = 0;
   FE_PROF(L, PF_STEP);
   // S (LDS, HFT tiles) = cat[h1, h2]: fused-encoder input, its skip connection AND the heads' input
@@ -537,7 +630,7 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
   ffor<2>([&](auto bc) {
     constexpr int br = decltype(bc)::v;
     f32x16 x[HBT], out[HBT], tin;
-    embed_tile<DM, br>(tin, xp, kp, m, L, half);
+    if (active) embed_tile<DM, br>(tin, xp, kp, m, L, half);
     FE_PROF(L, PF_EMBED);
     const int nbb = br == 0 ? A.nb_branch : A.nb_branch1;
     // descriptors: projection 4, layers 4 each, output 1
@@ -546,7 +639,7 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
     if (tid < DM::GB) L.gskip[tid] = L.gcur[tid];        // read in the fourth interval of a layer: barriers in between
     // the skip tiles wait in the upper half of S (free until this branch's own output goes there, or -- branch 0 --
     // until branch 1's does): 16*HBT registers less across the layers
-    ffor<HBT>([&](auto t) { park_tile(S, HBT + decltype(t)::v, x[decltype(t)::v], tid); });
+    if (active) ffor<HBT>([&](auto t) { park_tile(S, HBT + decltype(t)::v, x[decltype(t)::v], tid); });
     for (int i = 0; i < nbb; ++i) {
       const int nx = desc_wx(L, i + 1 < nbb ? li + 4 + 2 : li + 4);
       EB::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, HBT + decltype(t)::v, tid); }, A.use_skip != 0, c, li, ci, nx,
@@ -557,7 +650,7 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
     if constexpr (br == 0) nx = desc_wx(L, li + 1);
     else nx = desc_wx(L, A.nb_fused_exec > 0 ? li + 1 + 2 : li + 1);
     EB::template output<HBT, DM::HB, (br == 0 || EF::CARRY)>(out, x, c, li, ci, nx, ring, tr);
-    ffor<HBT>([&](auto t) { park_tile(S, br * HBT + decltype(t)::v, out[decltype(t)::v], tid); });
+    if (active) ffor<HBT>([&](auto t) { park_tile(S, br * HBT + decltype(t)::v, out[decltype(t)::v], tid); });
     if (tid < DM::GB) L.gcat[br * DM::GB + tid] = L.gcur[tid];
   });
   // ---- fused encoder, no projection (K2: nb_fused_exec = constructed - 1).  gcat / gcur / gskip are written and read
@@ -565,7 +658,7 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
   if (tid < DM::GF) { L.gcur[tid] = L.gcat[tid]; L.gskip[tid] = L.gcat[tid]; }
   if constexpr (TR::on) tr.vec(L.gcat, DM::GF, tid);
   f32x16 x[HFT], f[HFT];
-  ffor<HFT>([&](auto t) { x[decltype(t)::v] = fetch_tile(S, decltype(t)::v, tid); });
+  if (active) ffor<HFT>([&](auto t) { x[decltype(t)::v] = fetch_tile(S, decltype(t)::v, tid); });
   for (int i = 0; i < A.nb_fused_exec; ++i) {
     const int nx = desc_wx(L, i + 1 < A.nb_fused_exec ? li + 4 + 2 : li + 4);
     EF::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, decltype(t)::v, tid); }, A.use_skip != 0, c, li, ci, nx, ring, tr);
@@ -776,8 +869,11 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
   __shared__ Lds L;
   __shared__ float4 S[DM::HFT * 4 * FE_THREADS];
   __shared__ float park_s[4][FE_THREADS];  // x (3) and k of this lane's particle while a forward runs
+  __shared__ float padv[12];               // drift (0..2) and logits (4..11) of the representative padded slot
+  __shared__ short order_s[32 * FE_WAVES];
   stagger_start(Gn.stagger, threadIdx.x, L.red);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = steer_wave((Gn.tiles & 2) != 0, threadIdx.x >> 6, lane, L.red);
+  const int tid = 64 * wave + lane, half = lane >> 5;
   constexpr int V = DM::V;
 #ifdef MMB_FE_PROF
   if (tid == 0) L.tlast = clock64();
@@ -786,17 +882,20 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
   __syncthreads();
   WRing<ring_depth_multi<DM>()> ring;
   ring_prime(ring, weight_rsrc(A.P), desc_wx(L, 0), lane * 16);
-  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+  for (int bi = blockIdx.x; bi < A.B; bi += gridDim.x) {
+    const int b = Gn.jet_order ? Gn.jet_order[bi] : bi;
     __syncthreads();
     if (tid == 0) L.cnt = (float)A.counts[b];
-    const int p = 32 * wave + (lane & 31);
-    const bool valid = p < A.N;
+    const int slot = 32 * wave + (lane & 31);
+    const bool valid = slot < A.N;
+    const int p = jet_order((Gn.tiles & 1) != 0, A.maskf + (int64_t)b * A.N, A.N, slot, wave, lane, L.red, order_s);
     const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
     const float m = valid ? A.maskf[gp] : 0.0f;
     float xp[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int d = 0; d < DM::DC; ++d) xp[d] = valid ? x[gp * DM::DC + d] : 0.0f;
     int kp = valid ? (int)k[gp] : 0;
+    const TilePlan tp = plan_tiles((Gn.tiles & 1) != 0, m, valid, wave, lane, L.red);
     for (int s = 0; s < Gn.steps; ++s) {
       __syncthreads();
       if (tid < DM::ET) L.temb[tid] = Gn.temb_steps[(int64_t)s * DM::ET + tid];
@@ -819,10 +918,15 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
       // Euler step on the drift head (solvers.py:21-25); padded slots move too (K3)
       park();
       NoTrain nt;
-      forward_jet<DM, true>(A, L, S, xp, kp, m, 0, hc, hd, tid, ring, nt);
+      forward_jet<DM, true>(A, L, S, xp, kp, m, 0, hc, hd, tid, ring, nt, tp.active);
       unpark();
       {
         float v[3] = {hc[0], hc[1], hc[2]};
+        if (tp.idle_any) {
+          if (tp.rep) { padv[0] = v[0]; padv[1] = v[1]; padv[2] = v[2]; }
+          __syncthreads();
+          if (!tp.active) { v[0] = padv[0]; v[1] = padv[1]; v[2] = padv[2]; }
+        }
         float w[4] = {0.f, 0.f, 0.f, 0.f};
         float sig = 0.0f;
         if (Gn.em) {                                     // both lane halves draw the same increments
@@ -854,10 +958,21 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
       __syncthreads();
       // tau-leap on the logits head, which sees the UPDATED x at the same t (solvers.py:59-81)
       park();
-      forward_jet<DM, true>(A, L, S, xp, kp, m, 1, hc, hd, tid, ring, nt);
+      forward_jet<DM, true>(A, L, S, xp, kp, m, 1, hc, hd, tid, ring, nt, tp.active);
       unpark();
       float r[V];
       gather_logits<DM>(hd, r, lane);
+      if (tp.idle_any) {
+        if (tp.rep) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) padv[4 + v] = r[v];
+        }
+        __syncthreads();
+        if (!tp.active) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) r[v] = padv[4 + v];
+        }
+      }
       kp = jump_step(r, kp, tt, Gn, s == Gn.steps - 1, valid, A.B, A.N, b, p, s, gp);
     }
     if (valid && half == 0) {
@@ -877,15 +992,16 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
 // Training (TR = Train) slots: projection 9, layers 8 each (the V logits of the output layer go to the caller).
 template <class DM, bool CT, class TR>
 __device__ __forceinline__ void forward_uni(const FusedArgs& A, Lds& L, float4* S, const float* tab, int kp, float m,
-                                            f32x16& hd, int tid, WRing<ring_depth_uni<DM>()>& ring, TR& nt) {
+                                            f32x16& hd, int tid, WRing<ring_depth_uni<DM>()>& ring, TR& nt,
+                                            bool active = true) {
   constexpr int HT = DM::HT, RD = ring_depth_uni<DM>();
   typedef Epic<HT, DM::ET, DM::G, RD, CT> E;
   const int lane = tid & 63, half = lane >> 5;
-  FCtx c{A.P, weight_rsrc(A.P), L, m, tid, lane, tid >> 6, half, lane * 16, A.ctab};
+  FCtx c{A.P, weight_rsrc(A.P), L, m, tid, lane, tid >> 6, half, lane * 16, A.ctab, active};
   int li = 0, ci = 0;
   FE_PROF(L, PF_STEP);
   f32x16 td[DM::EDT];
-  ffor<DM::EDT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+  if (active) ffor<DM::EDT>([&](auto tc) { constexpr int t = decltype(tc)::v;
     ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
       const float4 e = *reinterpret_cast<const float4*>(tab + kp * DM::EDP + 32 * t + 8 * q + 4 * half);
       td[t][4 * q + 0] = truncf(e.x * m); td[t][4 * q + 1] = truncf(e.y * m);      // quirk Q1
@@ -897,7 +1013,7 @@ __device__ __forceinline__ void forward_uni(const FusedArgs& A, Lds& L, float4* 
   E::template project<DM::EDT>(x, [&](auto fc) -> const f32x16& { return td[decltype(fc)::v]; }, c, li, ci, wx_after_proj,
                                ring, nt);
   if (tid < DM::G) L.gskip[tid] = L.gcur[tid];
-  ffor<HT>([&](auto t) { park_tile(S, decltype(t)::v, x[decltype(t)::v], tid); });
+  if (active) ffor<HT>([&](auto t) { park_tile(S, decltype(t)::v, x[decltype(t)::v], tid); });
   for (int i = 0; i < nb; ++i) {
     const int nx = desc_wx(L, i + 1 < nb ? li + 4 + 2 : li + 4);
     E::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, decltype(t)::v, tid); }, A.use_skip != 0, c, li, ci, nx, ring, nt);
@@ -1009,8 +1125,11 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
   __shared__ Lds L;
   __shared__ float4 S[DM::HT * 4 * FE_THREADS];
   __shared__ __attribute__((aligned(16))) float tab[DM::V * DM::EDP];
+  __shared__ float padv[8];                // logits of the representative padded slot (TilePlan)
+  __shared__ short order_s[32 * FE_WAVES];
   stagger_start(Gn.stagger, threadIdx.x, L.red);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = steer_wave((Gn.tiles & 2) != 0, threadIdx.x >> 6, lane, L.red);
+  const int tid = 64 * wave + lane, half = lane >> 5;
 #ifdef MMB_FE_PROF
   if (tid == 0) L.tlast = clock64();
 #endif
@@ -1019,14 +1138,17 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
   __syncthreads();
   WRing<ring_depth_uni<DM>()> ring;
   ring_prime(ring, weight_rsrc(A.P), desc_wx(L, 0), lane * 16);
-  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+  for (int bi = blockIdx.x; bi < A.B; bi += gridDim.x) {
+    const int b = Gn.jet_order ? Gn.jet_order[bi] : bi;
     __syncthreads();
     if (tid == 0) L.cnt = (float)A.counts[b];
-    const int p = 32 * wave + (lane & 31);
-    const bool valid = p < A.N;
+    const int slot = 32 * wave + (lane & 31);
+    const bool valid = slot < A.N;
+    const int p = jet_order((Gn.tiles & 1) != 0, A.maskf + (int64_t)b * A.N, A.N, slot, wave, lane, L.red, order_s);
     const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
     const float m = valid ? A.maskf[gp] : 0.0f;
     int kp = valid ? (int)k[gp] : 0;
+    const TilePlan tp = plan_tiles((Gn.tiles & 1) != 0, m, valid, wave, lane, L.red);
     for (int s = 0; s < Gn.steps; ++s) {
       __syncthreads();
       if (tid < DM::ET) L.temb[tid] = Gn.temb_steps[(int64_t)s * DM::ET + tid];
@@ -1034,9 +1156,20 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
       A.ctab = Gn.ctab_steps + (int64_t)s * Gn.n_ctab * 128;
       f32x16 hd;
       NoTrain nt;
-      forward_uni<DM, true>(A, L, S, tab, kp, m, hd, tid, ring, nt);
+      forward_uni<DM, true>(A, L, S, tab, kp, m, hd, tid, ring, nt, tp.active);
       float r[8];
       gather8(hd, r, lane);
+      if (tp.idle_any) {
+        if (tp.rep) {
+#pragma unroll
+          for (int v = 0; v < 8; ++v) padv[v] = r[v];
+        }
+        __syncthreads();
+        if (!tp.active) {
+#pragma unroll
+          for (int v = 0; v < 8; ++v) r[v] = padv[v];
+        }
+      }
       kp = jump_step(r, kp, Gn.times[s], Gn, s == Gn.steps - 1, valid, A.B, A.N, b, p, s, gp);
     }
     if (valid && half == 0) k[gp] = kp;
@@ -1049,6 +1182,11 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
 static int stagger_cycles(int dflt) {
   const char* e = getenv("MMB_STAGGER");
   return e ? atoi(e) : dflt;
+}
+// MMB_GEN_TILES=<bits> (developer switch; default 3): bit 0 idle tiles of padded slots, bit 1 tile-to-SIMD steering
+static int gen_tiles() {
+  const char* e = getenv("MMB_GEN_TILES");
+  return e ? atoi(e) : 3;
 }
 static int check_fused(const char* name, int B, int N, const void* P, const void* D, const void* maskf,
                        const void* counts, int n_desc) {
@@ -1075,11 +1213,11 @@ extern "C" int mmb_fused_uni_forward_w5(int, int, int, const float*, const int32
                                         const int32_t*, const int64_t*, const float*, int64_t, float*, void*);
 extern "C" int mmb_fused_uni_generate_w5(int, int, int, const float*, const int32_t*, int, int, int, const float*,
                                          const int32_t*, int64_t*, int, const float*, const float*, const float*, int, float,
-                                         int, float, const float*, uint64_t, uint64_t, void*);
+                                         int, float, const float*, uint64_t, uint64_t, const int32_t*, void*);
 extern "C" int mmb_fused_epic_generate_w5(int, int, int, const float*, const int32_t*, int, int, int, int, int, int, int,
                                           const float*, const int32_t*, float*, int64_t*, int, const float*, const float*,
                                           const float*, int, float, int, float, const float*, uint64_t, uint64_t, int, float,
-                                          const float*, void*);
+                                          const float*, const int32_t*, void*);
 extern "C" int mmb_fused_epic_train_forward_w5(int, int, int, const float*, const int32_t*, int, int, int, int, int, int, int,
                                                const float*, const int32_t*, const float*, const int64_t*, const float*,
                                                int64_t, const void*, int, float, uint64_t, uint64_t, float*, float*, void*);
@@ -1225,10 +1363,11 @@ extern "C" int mmb_fused_uni_generate(int variant, int B, int N, const float* pa
                                       const int32_t* counts, int64_t* k, int steps, const float* times,
                                       const float* temb_steps, const float* ctab_steps, int n_ctab, float dt,
                                       int thermo_kind, float gamma, const float* delta_n, uint64_t seed,
-                                      uint64_t offset, void* stream) {
+                                      uint64_t offset, const int32_t* jet_order, void* stream) {
 #if MMB_FE_WAVES == 4
   if (N > 128) return mmb_fused_uni_generate_w5(variant, B, N, packed, desc, num_blocks, use_skip, off_table, maskf, counts, k, steps,
-                                                times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, gamma, delta_n, seed, offset, stream);
+                                                times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, gamma, delta_n, seed, offset,
+                                                jet_order, stream);
 #endif
   int rc = check_fused("mmb_fused_uni_generate", B, N, packed, desc, maskf, counts, n_desc_uni(num_blocks));
   if (rc) return rc;
@@ -1239,7 +1378,7 @@ extern "C" int mmb_fused_uni_generate(int variant, int B, int N, const float* pa
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), num_blocks, 0, use_skip, 0, 0, off_table, B, N,
               maskf, counts, 0, n_desc_uni(num_blocks)};
   GenArgs Gn{steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, (float)(-(double)8 * (double)gamma), delta_n,
-             seed, offset, 0, 0.0f, nullptr, stagger_cycles(0)};
+             seed, offset, 0, 0.0f, nullptr, stagger_cycles(0), gen_tiles(), jet_order};
   const int grid = B < 4096 ? B : 4096;
   switch (variant) {
     case 0: hipLaunchKernelGGL(fused_uni_generate_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k); break;
@@ -1251,6 +1390,32 @@ extern "C" int mmb_fused_uni_generate(int variant, int B, int N, const float* pa
 }
 
 #if MMB_FE_WAVES == 4
+// ---- launch order of the jets of a generation call ------------------------------------------------
+// A jet costs what its working tiles cost (TilePlan), and a call has few jets per workgroup slot (1024 jets on 512
+// slots): in their natural order the last slots to finish hold two long jets while the rest of the chip idles.  Longest
+// first: the jets sorted by particle count, descending (a counting sort in one workgroup; jets of one count in any
+// order -- a jet's result does not depend on the workgroup that computes it).
+__global__ void __launch_bounds__(1024) jet_schedule_kernel(const int32_t* __restrict__ counts, int B, int32_t* __restrict__ order) {
+  __shared__ int bin[256];
+  const int tid = threadIdx.x;
+  if (tid < 256) bin[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < B; i += 1024) atomicAdd(&bin[255 - min(max(counts[i], 0), 255)], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int c = 0; c < 256; ++c) { const int n = bin[c]; bin[c] = run; run += n; }
+  }
+  __syncthreads();
+  for (int i = tid; i < B; i += 1024) order[atomicAdd(&bin[255 - min(max(counts[i], 0), 255)], 1)] = i;
+}
+
+extern "C" int mmb_jet_schedule(int B, const int32_t* counts, int32_t* order, void* stream) {
+  MMB_REQUIRE(B > 0 && counts && order, "mmb_jet_schedule: needs B > 0 and two buffers of B int32 (got B=%d)", B);
+  hipLaunchKernelGGL(jet_schedule_kernel, dim3(1), dim3(1024), 0, as_stream(stream), counts, B, order);
+  return check_launch("mmb_jet_schedule");
+}
+
 // ==================================================================== MultiModalMLP (toy, S1) ====
 // The whole generation loop of the toy hybrid experiment (notebooks/data_toys.ipynb cell 3 inside
 // multimodal_bridge_matching.py:227-259) in ONE launch: the layered path needs 16 launches per grid point and is
@@ -1455,11 +1620,12 @@ extern "C" int mmb_fused_epic_generate(int variant, int B, int N, const float* p
                                        int steps, const float* times, const float* temb_steps,
                                        const float* ctab_steps, int n_ctab, float dt,
                                        int thermo_kind, float gamma, const float* delta_n, uint64_t seed,
-                                       uint64_t offset, int em, float em_sigma, const float* delta_w, void* stream) {
+                                       uint64_t offset, int em, float em_sigma, const float* delta_w,
+                                       const int32_t* jet_order, void* stream) {
 #if MMB_FE_WAVES == 4
   if (N > 128) return mmb_fused_epic_generate_w5(variant, B, N, packed, desc, nb_branch, nb_branch1, nb_fused_exec, use_skip, off_cw, off_cb,
                                                  off_table, maskf, counts, x, k, steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind,
-                                                 gamma, delta_n, seed, offset, em, em_sigma, delta_w, stream);
+                                                 gamma, delta_n, seed, offset, em, em_sigma, delta_w, jet_order, stream);
 #endif
   int rc = check_fused("mmb_fused_epic_generate", B, N, packed, desc, maskf, counts, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec));
   if (rc) return rc;
@@ -1470,7 +1636,7 @@ extern "C" int mmb_fused_epic_generate(int variant, int B, int N, const float* p
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
               off_table, B, N, maskf, counts, nb_branch1, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec)};
   GenArgs Gn{steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, (float)(-(double)8 * (double)gamma), delta_n, seed, offset,
-             em, em_sigma, delta_w, stagger_cycles(0)};
+             em, em_sigma, delta_w, stagger_cycles(0), gen_tiles(), jet_order};
   const int grid = B < 4096 ? B : 4096;
   switch (variant) {
     case 0: hipLaunchKernelGGL(fused_generate_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k); break;

@@ -87,7 +87,8 @@ SIGNATURES = {
                                 C.c_int, C.c_int, c_f32p, c_i32p, c_f32p, c_i64p, C.c_int, c_f32p, c_f32p, c_f32p,
                                 C.c_int, C.c_float,
                                 C.c_int, C.c_float, c_f32p, C.c_uint64, C.c_uint64, C.c_int, C.c_float, c_f32p,
-                                c_stream],
+                                c_i32p, c_stream],
+    "mmb_jet_schedule": [C.c_int, c_i32p, c_i32p, c_stream],
     "mmb_jet_observables": [C.c_int, C.c_int, C.c_int, c_f32p, c_i64p, c_f32p, c_f32p, c_stream],
     "mmb_postprocess": [C.c_int64, C.c_int, C.c_int, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, C.c_int, c_stream],
     "mmb_postprocess_onehot": [C.c_int64, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p,
@@ -100,7 +101,7 @@ SIGNATURES = {
                               c_i64p, c_f32p, C.c_int64, c_f32p, c_stream],
     "mmb_fused_uni_generate": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, c_f32p, c_i32p,
                                c_i64p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_float, C.c_int, C.c_float,
-                               c_f32p, C.c_uint64, C.c_uint64, c_stream],
+                               c_f32p, C.c_uint64, C.c_uint64, c_i32p, c_stream],
     "mmb_attention_fwd": [C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, C.c_int, c_f32p, C.c_int64,
                           c_f32p, c_stream],
     "mmb_attention_bwd": [C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, C.c_int, c_f32p, C.c_int64,

@@ -687,6 +687,30 @@ def train_backward(pack, pbwd, mi, slots, n_slots, drop_p, seed, offset0):
          _fl(drop_p), seed, offset0, stream())
 
 
+def jet_schedule(mi):
+    """(B) int32 launch order of the jets of a generation call: longest first (csrc/fused_epic.hip: jet_schedule_kernel);
+    kept with the mask it was computed from."""
+    order = getattr(mi, "_order", None)
+    if order is None:
+        order = torch.empty(mi.B, dtype=torch.int32, device=mi.maskf.device)
+        call("mmb_jet_schedule", mi.B, i32(mi.counts), i32(order), stream())
+        mi._order = order
+    return order
+
+
+def working_tiles(counts, N):
+    """(B) number of 32-particle tiles of each jet that do per-particle work in the generation kernels (TilePlan in
+    csrc/fused_epic.hip): the tiles its real particles fill, plus one when no padded slot sits next to a real one."""
+    import os
+    n = counts.to(torch.int64)
+    all_tiles = (N + 31) // 32
+    if not (int(os.environ.get("MMB_GEN_TILES", "3")) & 1):
+        return torch.full_like(n, all_tiles)
+    t = (n + 31) // 32
+    t = t + ((n % 32 == 0) & (n < N)).to(torch.int64)
+    return t.clamp(max=all_tiles)
+
+
 def generate(pack, mi, x, k, times, temb_steps, dt, thermo_kind, gamma, delta_n=None, seed=0, offset=0, ctab=None,
              em_sigma=None, delta_w=None):
     """In-place generation loop on x (B,N,3) and k (B,N,1).  em_sigma is None -> Euler, else
@@ -699,7 +723,8 @@ def generate(pack, mi, x, k, times, temb_steps, dt, thermo_kind, gamma, delta_n=
          pack["nb_branch1"], pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"], pack["off_table"],
          f32(mi.maskf), i32(mi.counts), f32(x, "x"), i64(k, "k"), times.numel(), f32(times, "times"), f32(temb_steps, "temb_steps"),
          f32(ctab, "ctab"), n_ctab, _fl(dt), thermo_kind, _fl(gamma), f32(delta_n, "delta_n"), seed, offset,
-         0 if em_sigma is None else 1, _fl(0.0 if em_sigma is None else em_sigma), f32(delta_w, "delta_w"), stream())
+         0 if em_sigma is None else 1, _fl(0.0 if em_sigma is None else em_sigma), f32(delta_w, "delta_w"),
+         i32(jet_schedule(mi)), stream())
 
 
 def forward_uni(pack, mi, k, temb, temb_stride=None):
@@ -722,7 +747,7 @@ def generate_uni(pack, mi, k, times, temb_steps, dt, thermo_kind, gamma, delta_n
     call("mmb_fused_uni_generate", pack["variant"], B, N, f32(pack["packed"]), i32(pack["desc"]), pack["num_blocks"],
          pack["use_skip"], pack["off_table"], f32(mi.maskf), i32(mi.counts), i64(k, "k"), times.numel(),
          f32(times, "times"), f32(temb_steps, "temb_steps"), f32(ctab, "ctab"), n_ctab, _fl(dt), thermo_kind,
-         _fl(gamma), f32(delta_n, "delta_n"), seed, offset, stream())
+         _fl(gamma), f32(delta_n, "delta_n"), seed, offset, i32(jet_schedule(mi)), stream())
 
 
 def algorithmic_flops_per_particle(model):

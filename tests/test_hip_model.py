@@ -701,3 +701,63 @@ def test_n150_generation_runs_the_fused_five_wave_kernels(golden, name, entry):
     if paths.continuous is not None:
         assert torch.isfinite(paths.continuous[1]).all()
     assert model.fused_training_available()                  # the training kernels have the five-wave build too
+
+
+@pytest.mark.parametrize("name", ["mm_mid", "S3", "S3_n150", "uni_mid", "S2", "S2_n150"])
+def test_idle_tiles_leave_generation_bit_identical(golden, name, monkeypatch):
+    """Tiles with nothing but padded slots stay idle in the generation kernels and take drift and logits from one
+    representative padded slot (csrc/fused_epic.hip: TilePlan).  Every slot of the result -- padded ones move too,
+    K3 -- must be bit-identical to the kernels that compute all tiles, whatever the multiplicity: tile edges, no padded
+    slot next to a real one, full jets, holes in the mask."""
+    from tensorclass import TensorMultiModal
+    from datamodules.datasets import DataCoupling
+    g = golden(name)
+    model = build(g, num_timesteps=6)
+    model.use_fused = True
+    N = g.t["mask"].shape[1]
+    uni = "xt" not in g.t
+    gen = torch.Generator().manual_seed(5)
+    ns = [min(n, N) for n in (1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, N - 1, N)] + torch.randint(1, N + 1, (51,), generator=gen).tolist()
+    B = len(ns) + 2
+    mask = torch.zeros(B, N, 1, dtype=torch.int64)
+    for b, n in enumerate(ns):
+        mask[b, :n] = 1
+    mask[-2, N // 3:N // 3 + 4] = 1          # not a prefix: real particles in the second tile only (four-tile clouds)
+    mask[-1, ::37] = 1                       # one real particle in every tile
+    k0 = torch.randint(0, 8, (B, N, 1), generator=gen) * mask
+    x0 = None if uni else torch.randn(B, N, 3, generator=gen) * mask
+
+    def run(bits):
+        monkeypatch.setenv("MMB_GEN_TILES", str(bits))
+        model.manual_seed(11)
+        src = TensorMultiModal(None, None if uni else x0.cuda(), k0.cuda(), mask.cuda())
+        state = TensorMultiModal(torch.zeros_like(src.mask), None if uni else src.continuous.clone(), src.discrete.clone(),
+                                 src.mask)
+        paths = model.simulate_dynamics(state, DataCoupling(src, TensorMultiModal(None, None, None, src.mask), None))
+        return (None if uni else paths.continuous[1].clone()), paths.discrete[1].clone()
+
+    x_all, k_all = run(0)
+    prefix = torch.arange(B) < len(ns)                      # a prefix mask keeps its slot order: nothing may move at all
+    m = mask.cuda() > 0
+    for bits in (1, 3):
+        xs, ks = run(bits)
+        assert torch.equal(ks[prefix], k_all[prefix]), f"{name}: k differs with MMB_GEN_TILES={bits}"
+        assert (ks == k_all).float().mean() > 0.999
+        if not uni:
+            assert torch.equal(xs[prefix], x_all[prefix]), f"{name}: x differs with MMB_GEN_TILES={bits}"
+            close(xs, x_all, rtol=1e-4, atol=2e-5)           # reordered slots: pooled sums in another order
+            assert (x_all[~m.expand_as(x_all)] != 0).any()  # padded slots moved (K3)
+
+
+def test_jet_schedule_is_a_longest_first_permutation():
+    """mmb_jet_schedule: the launch order of a generation call -- every jet once, particle counts descending."""
+    from mmb_hip import ops, fused
+    gen = torch.Generator().manual_seed(3)
+    for B in (1, 7, 1024, 5000):
+        mask = (torch.rand(B, 150, 1, generator=gen) < torch.rand(B, 1, 1, generator=gen)).long().cuda()
+        mi = ops.mask_prepare(mask)
+        order = fused.jet_schedule(mi).long()
+        assert torch.equal(torch.sort(order).values, torch.arange(B, device="cuda"))
+        c = mi.counts[order]
+        assert bool((c[1:] <= c[:-1]).all())
+        assert fused.jet_schedule(mi) is mi._order               # computed once per mask

@@ -493,14 +493,19 @@ int mmb_fused_epic_forward(int variant, int B, int N, const float* packed, const
  * local.2 pre/out, pooled, global.0 pre/out, global.2 pre/out; per layer: pooled, fc_glob1 out, g', g_out, sign words
  * of fc_loc1, fc_loc1 out, sign words of l_out, l_out (sign words: 256 x 64-bit per jet: bit 16t+r of thread i = sign of the leaky-relu
  * input behind register r of tile t); output], the concatenated global vector, fused encoder [layers; output], heads [.0 pre/out] x 2.
- * head_c (B*N,3), head_d (B*N,8). */
+ * head_c (B*N,3), head_d (B*N,8).
+ * Padded slots: a 32-particle tile without a real particle is idle in both kernels of the pair (the real particles of a
+ * jet are put first inside the kernels; rows stay indexed by the true slot).  Its rows of the saved activations are
+ * left unwritten -- allocate those buffers zeroed once: the weight-gradient GEMMs multiply them by gradient rows that
+ * are exactly zero, so they only have to be finite -- and its heads are written as zeros (the losses are masked).
+ * jet_order (B) | NULL: launch order of the jets (mmb_jet_schedule), as for mmb_fused_epic_generate. */
 int mmb_fused_epic_train_forward(int variant, int B, int N, const float* packed, const int32_t* desc,
                                  int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip,
                                  int off_cw, int off_cb, int off_table,
                                  const float* maskf, const int32_t* counts,
                                  const float* x, const int64_t* k, const float* temb, int64_t temb_stride,
                                  const void* slots, int n_slots, float drop_p, uint64_t seed, uint64_t offset0,
-                                 float* head_c, float* head_d, void* stream);
+                                 float* head_c, float* head_d, const int32_t* jet_order, void* stream);
 
 /* Reverse pass of that forward for every jet in ONE launch (what loss.backward() does to the encoder in the
  * reference's training_step): gradients of activations stay in registers; the kernel reads the saved activations and
@@ -517,7 +522,7 @@ int mmb_fused_epic_train_backward(int variant, int B, int N, const float* packed
                                   int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip,
                                   const float* maskf, const int32_t* counts,
                                   const void* slots, int n_slots, float drop_p, uint64_t seed, uint64_t offset0,
-                                  void* stream);
+                                  const int32_t* jet_order, void* stream);
 
 /* The same pair for the discrete-only UniModalEPiC (multimodal_epic.py:44-64; one EPiC encoder with projection on
  * cat[t, t, k_emb] whose output layer emits the V logits).  Forward slots: projection 9, layers 8 each.  Backward
@@ -527,11 +532,11 @@ int mmb_fused_uni_train_forward(int variant, int B, int N, const float* packed, 
                                 const float* maskf, const int32_t* counts, const int64_t* k,
                                 const float* temb, int64_t temb_stride,
                                 const void* slots, int n_slots, float drop_p, uint64_t seed, uint64_t offset0,
-                                float* head_d, void* stream);
+                                float* head_d, const int32_t* jet_order, void* stream);
 int mmb_fused_uni_train_backward(int variant, int B, int N, const float* packed_bwd, const int32_t* desc_bwd,
                                  int num_blocks, int use_skip, const float* maskf, const int32_t* counts,
                                  const void* slots, int n_slots, float drop_p, uint64_t seed, uint64_t offset0,
-                                 void* stream);
+                                 const int32_t* jet_order, void* stream);
 
 /* simulate_dynamics (multimodal_bridge_matching.py:227-259) in ONE launch: per grid point
  * [forward -> Euler step on x (solvers.py:21-25)] [forward -> telegraph rates (bridges.py:137-163)

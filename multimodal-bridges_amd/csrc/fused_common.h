@@ -873,4 +873,80 @@ typedef UniDims<64, 64, 64, 16, 8> UniH64;           // 2: Et64 Ed64 H64 G16
 typedef UniDims<32, 32, 32, 16, 8> UniH32;           // 3: Et32 Ed32 H32 G16
 constexpr int N_UNI_VARIANTS = 4;
 
+// Which of a jet's 32-particle tiles do per-particle work in the generation loops and the training kernels.  A padded slot never enters a pooled
+// sum (the mask) and its own inputs are zero (embedder.py:74-80 + apply_mask): every padded slot of a jet carries the
+// same row through the encoder.  The solvers move padded slots all the same (K3), so that row is still needed -- once:
+// a tile with nothing but padded slots stays idle and takes drift and logits of every grid point from one
+// representative padded slot of an active tile (rows of an MFMA product do not depend on their position: bit-identical).
+// AOJ multiplicities (48 particles on average, 82 % of the jets below 65) leave two of four tiles idle on average.
+// Training (need_rep = false): the loss is masked, so nothing of a padded slot is needed at all -- its activations
+// are multiplied by gradients that are exactly zero.
+struct TilePlan {
+  bool active;       // wave-uniform: this wave's tile computes
+  bool idle_any;     // workgroup-uniform: some tile with valid slots is idle, the representative publishes the heads
+  bool rep;          // this lane holds the representative padded slot (lane half 0)
+};
+__device__ __forceinline__ TilePlan plan_tiles(bool on, bool need_rep, float m, bool valid, int wave, int lane, int* red) {
+  const unsigned long long pad_b = __ballot(valid && m == 0.0f);
+  const bool real = __ballot(m != 0.0f) != 0;
+  __syncthreads();                                       // the readers of red's last use
+  if (lane == 0) red[wave] = (real ? 1 : 0) | (pad_b != 0 ? 2 : 0);
+  __syncthreads();
+  int act = 0, pad = 0;
+  for (int w = 0; w < FE_WAVES; ++w) { const int f = red[w]; act |= (f & 1) << w; pad |= ((f >> 1) & 1) << w; }
+  int rep = -1;
+  if (act & pad) rep = __ffs(act & pad) - 1;
+  else if (pad && (need_rep || act == 0)) { rep = __ffs(pad) - 1; act |= 1 << rep; }   // no padded slot next to a real one: one more tile works
+  if (!on) { act = (1 << FE_WAVES) - 1; rep = -1; }
+  TilePlan t;
+  t.active = __builtin_amdgcn_readfirstlane((act >> wave) & 1) != 0;
+  t.idle_any = __builtin_amdgcn_readfirstlane(pad & ~act) != 0;
+  t.rep = wave == rep && lane == (int)__ffsll((long long)pad_b) - 1;
+  return t;
+}
+
+// Slot order of a jet inside the generation kernels: real particles first (stable), padded slots behind them, so that a
+// short jet fills whole tiles and leaves whole tiles idle whatever slots its mask marks -- the reference's sources permute
+// every mask (distributions/noise.py:36-37).  EPiC is permutation-equivariant: a particle's row does not depend on its
+// slot, only the pooled sums move in their last bits with the order of summation (not at all for a mask that already is
+// a prefix).  Injected noise and the Philox keys stay indexed by the true slot.  Returns the true slot behind `slot`.
+__device__ __forceinline__ int jet_order(bool on, const float* maskf, int N, int slot, int wave, int lane, int* red,
+                                         short* order) {
+  if (!on) return slot;
+  const bool valid = slot < N;
+  const float m = valid ? maskf[slot] : 0.0f;
+  const unsigned real_b = (unsigned)__ballot(m != 0.0f), pad_b = (unsigned)__ballot(valid && m == 0.0f);   // lanes 0..31
+  __syncthreads();                                       // the readers of red's last use
+  if (lane == 0) red[wave] = __popc(real_b) | (__popc(pad_b) << 8);
+  __syncthreads();
+  int n_real = 0, real_before = 0, pad_before = 0;
+  for (int w = 0; w < FE_WAVES; ++w) {
+    const int f = red[w];
+    n_real += f & 255;
+    if (w < wave) { real_before += f & 255; pad_before += f >> 8; }
+  }
+  const unsigned below = (1u << (lane & 31)) - 1u;
+  const int pos = m != 0.0f ? real_before + __popc(real_b & below) : n_real + pad_before + __popc(pad_b & below);
+  if (valid && lane < 32) order[pos] = (short)slot;
+  __syncthreads();
+  return valid ? order[slot] : slot;
+}
+
+// Two jets share a CU, one wave of each on every SIMD, and most jets leave tiles idle: which SIMDs the working tiles sit
+// on decides whether the two jets' GEMMs meet on the same matrix pipes.  Tile t goes to SIMD t in the workgroup that
+// holds the first wave slot and to SIMD 3 - t in the other one (measured with two working tiles per jet: 62 ms -> 56 ms
+// for the S3 loop).  Returns the tile of this wave; the hardware wave order when the four waves do not sit on four SIMDs.
+__device__ __forceinline__ int steer_wave(bool on, int hw_wave, int lane, int* red) {
+  if (FE_WAVES != 4 || !on) return hw_wave;
+  const unsigned id = __builtin_amdgcn_s_getreg((5 << 11) | 4);      // HW_REG_HW_ID[5:0]: wave slot [3:0], SIMD [5:4]
+  if (lane == 0) red[hw_wave] = (int)id;
+  __syncthreads();
+  int seen = 0;
+  for (int w = 0; w < 4; ++w) seen |= 1 << ((red[w] >> 4) & 3);
+  const int flip = red[0] & 1, simd = (int)(id >> 4) & 3;
+  const int wave = seen == 0xF ? (flip ? 3 - simd : simd) : hw_wave;
+  __syncthreads();
+  return __builtin_amdgcn_readfirstlane(wave);
+}
+
 }  // namespace mmb

@@ -62,14 +62,18 @@ enum { PF_EMBED = 0, PF_POOL, PF_GLOB1, PF_GLOB2, PF_DVEC, PF_LOC1, PF_LOC2, PF_
 
 // ------------------------------------------------------------------ one EPiC encoder ----
 // What every stage of a forward needs besides its tiles
-struct FCtx {
+// ACT: this wave's tile takes part in the per-particle work (TilePlan).  A compile-time property of the context: an idle
+// tile runs its own, small instantiation of the forward (same barriers, its share of the per-jet chain, no GEMMs), so
+// that the working tiles' instruction stream is the one it was before tiles could be idle.
+template <bool ACT>
+struct FCtxT {
+  static constexpr bool active = ACT;
   const float* P;          // packed parameters
   WRsrc R;                 // ... as a buffer resource
   Lds& L;
   float m;                 // this lane's particle mask
   int tid, lane, wave, half, lane16;
   const float* ctab;       // (n_c_layers,128) time vectors W_t temb of the CURRENT grid point (CT kernels)
-  bool active;             // wave-uniform: this wave's tile takes part in the per-particle work (see TilePlan)
 };
 
 // An idle tile contributes exact zeros to the pooled sums
@@ -174,8 +178,8 @@ struct Epic {
   // leaky-relu input behind l_out), l_out.
   // Five intervals separated by barriers; every global load of the chain is requested in the first one:
   //   I0 pool partials | I1 pooled vector | I2 fc_glob1 (+ time vector, staged vectors) | I3 fc_glob2 | I4 d-vector, g
-  template <typename SkipFn, class TR>
-  static __device__ __forceinline__ void layer(f32x16 (&x)[HT], SkipFn&& skipf, bool use_skip, FCtx& c, int& li, int& ci,
+  template <typename SkipFn, class TR, class CX>
+  static __device__ __forceinline__ void layer(f32x16 (&x)[HT], SkipFn&& skipf, bool use_skip, CX& c, int& li, int& ci,
                                                int next_wx, WRing<RD>& ring, TR& tr) {
     Lds& L = c.L;
     const int tid = c.tid, lane = c.lane, wave = c.wave, half = c.half;
@@ -195,7 +199,7 @@ struct Epic {
     if constexpr (!CT) MVT::template prefetch<false>(wt, c.R, fld<F_WT>(dv.d[2]), 0, tid);
     ++ci;
     FE_PROF(L, PF_X1);
-    if (c.active) pool_partials<HT>(x, c.m, L.partial, wave, lane);
+    if constexpr (CX::active) pool_partials<HT>(x, c.m, L.partial, wave, lane);
     else zero_partials(L.partial, wave, lane);
     FE_PROF(L, PF_X2);
     typename MVB::Pre wb;
@@ -260,7 +264,7 @@ struct Epic {
 #endif
     FE_PROF(L, PF_DVEC);
     prio_gemm();
-    if (c.active) {
+    if constexpr (CX::active) {
     f32x16 lh[HT];
     acc_init<HT>(lh, c.m, L.cvec, L.dvec, half);
     mma_r<HT, HT, RD, true>(lh, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, c.R, fld<F_WX>(dv.d[2]), fld<F_WX>(dv.d[3]), c.lane16, ring);
@@ -299,6 +303,8 @@ struct Epic {
         ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; x[t][r] += sk[r]; });
       } });
     if constexpr (TR::on) tr.template tiles<HT>(x, half);
+    } else {
+      if constexpr (TR::on) { tr.si += 4; if (tr.drop_p > 0.0f) ++tr.off; }       // the slots and the Philox call an idle tile skips
     }
     FE_PROF(L, PF_EPI);
   }
@@ -306,8 +312,8 @@ struct Epic {
   // output layer: wn Linear on cat[t, x, g] (epic.py:93-96); OTO output tiles, OW = true output width
   // Training slot: out (only when OW is a whole number of tiles).
   // PFN: the GEMM after this one takes its first fragments from this one's tail (false: it primes the ring itself)
-  template <int OTO, int OW, bool PFN, class TR>
-  static __device__ __forceinline__ void output(f32x16 (&out)[OTO], const f32x16 (&x)[HT], FCtx& c, int& li, int& ci,
+  template <int OTO, int OW, bool PFN, class TR, class CX>
+  static __device__ __forceinline__ void output(f32x16 (&out)[OTO], const f32x16 (&x)[HT], CX& c, int& li, int& ci,
                                                 int next_wx, WRing<RD>& ring, TR& tr) {
     Lds& L = c.L;
     const int tid = c.tid, lane = c.lane, wave = c.wave, half = c.half;
@@ -333,18 +339,20 @@ struct Epic {
     }
     sync_pin();
     prio_gemm();
-    if (c.active) {
+    if constexpr (CX::active) {
     acc_init<OTO>(out, c.m, L.cvec, L.dvec, half);
     mma_r<HT, OTO, RD, PFN>(out, [&](auto fc) -> const f32x16& { return x[decltype(fc)::v]; }, c.R, fld<F_WX>(dv.d[0]), next_wx, c.lane16, ring);
     if constexpr (TR::on && OW == 32 * OTO) tr.template tiles<OTO>(out, half);
+    } else {
+      if constexpr (TR::on && OW == 32 * OTO) tr.si += 1;
     }
     FE_PROF(L, PF_OUT);
   }
 
   // EPiCProjection (epic.py:145-159) from KIN padded input tiles delivered by xin(IF<t>)
   // Training slots: p0 pre, p0 out, p2 pre, p2 out, pooled, q0 pre, q0 out, q2 pre, q2 out.
-  template <int KIN, typename InFn, class TR>
-  static __device__ __forceinline__ void project(f32x16 (&x)[HT], InFn&& xin, FCtx& c, int& li, int& ci, int next_wx,
+  template <int KIN, typename InFn, class TR, class CX>
+  static __device__ __forceinline__ void project(f32x16 (&x)[HT], InFn&& xin, CX& c, int& li, int& ci, int next_wx,
                                                  WRing<RD>& ring, TR& tr) {
     Lds& L = c.L;
     const int tid = c.tid, lane = c.lane, wave = c.wave, half = c.half;
@@ -370,7 +378,7 @@ struct Epic {
     if (wave == 2) stage_commit(st, L.bvec, H, lane);
     sync_pin();
     prio_gemm();
-    if (c.active) {
+    if constexpr (CX::active) {
     f32x16 h[HT];
     acc_init<HT>(h, c.m, L.cvec, L.dvec, half);
     mma_r<KIN, HT, RD, true>(h, xin, c.R, fld<F_WX>(dv.d[0]), fld<F_WX>(dv.d[1]), c.lane16, ring);
@@ -382,12 +390,14 @@ struct Epic {
     if constexpr (TR::on) tr.template tiles<HT>(x, half);
     act_tiles<HT, MMB_ACT_GELU>(x);
     if constexpr (TR::on) tr.template tiles<HT>(x, half);
+    } else {
+      if constexpr (TR::on) tr.si += 4;
     }
     FE_PROF(L, PF_PROJ_MMA);
     prio_chain();
     typename MVQ0::Pre wq0;
     if constexpr (CARRY) MVQ0::prefetch(wq0, c.R, fld<F_WT>(dv.d[2]), fld<F_B>(dv.d[2]), tid);
-    if (c.active) pool_partials<HT>(x, c.m, L.partial, wave, lane);
+    if constexpr (CX::active) pool_partials<HT>(x, c.m, L.partial, wave, lane);
     else zero_partials(L.partial, wave, lane);
     typename MV<H, G>::Pre wq2;
     if constexpr (CARRY) MV<H, G>::prefetch(wq2, c.R, fld<F_WT>(dv.d[3]), fld<F_B>(dv.d[3]), tid);
@@ -447,80 +457,6 @@ __device__ __forceinline__ void stagger_start(int cycles, int tid, int* flag) {
 }
 
 
-// Which of a jet's 32-particle tiles do per-particle work in the generation loops.  A padded slot never enters a pooled
-// sum (the mask) and its own inputs are zero (embedder.py:74-80 + apply_mask): every padded slot of a jet carries the
-// same row through the encoder.  The solvers move padded slots all the same (K3), so that row is still needed -- once:
-// a tile with nothing but padded slots stays idle and takes drift and logits of every grid point from one
-// representative padded slot of an active tile (rows of an MFMA product do not depend on their position: bit-identical).
-// AOJ multiplicities (48 particles on average, 82 % of the jets below 65) leave two of four tiles idle on average.
-struct TilePlan {
-  bool active;       // wave-uniform: this wave's tile computes
-  bool idle_any;     // workgroup-uniform: some tile with valid slots is idle, the representative publishes the heads
-  bool rep;          // this lane holds the representative padded slot (lane half 0)
-};
-__device__ __forceinline__ TilePlan plan_tiles(bool on, float m, bool valid, int wave, int lane, int* red) {
-  const unsigned long long pad_b = __ballot(valid && m == 0.0f);
-  const bool real = __ballot(m != 0.0f) != 0;
-  __syncthreads();                                       // the readers of red's last use
-  if (lane == 0) red[wave] = (real ? 1 : 0) | (pad_b != 0 ? 2 : 0);
-  __syncthreads();
-  int act = 0, pad = 0;
-  for (int w = 0; w < FE_WAVES; ++w) { const int f = red[w]; act |= (f & 1) << w; pad |= ((f >> 1) & 1) << w; }
-  int rep = -1;
-  if (act & pad) rep = __ffs(act & pad) - 1;
-  else if (pad) { rep = __ffs(pad) - 1; act |= 1 << rep; }     // no padded slot next to a real one: one more tile works
-  if (!on) { act = (1 << FE_WAVES) - 1; rep = -1; }
-  TilePlan t;
-  t.active = __builtin_amdgcn_readfirstlane((act >> wave) & 1) != 0;
-  t.idle_any = __builtin_amdgcn_readfirstlane(pad & ~act) != 0;
-  t.rep = wave == rep && lane == (int)__ffsll((long long)pad_b) - 1;
-  return t;
-}
-
-// Slot order of a jet inside the generation kernels: real particles first (stable), padded slots behind them, so that a
-// short jet fills whole tiles and leaves whole tiles idle whatever slots its mask marks -- the reference's sources permute
-// every mask (distributions/noise.py:36-37).  EPiC is permutation-equivariant: a particle's row does not depend on its
-// slot, only the pooled sums move in their last bits with the order of summation (not at all for a mask that already is
-// a prefix).  Injected noise and the Philox keys stay indexed by the true slot.  Returns the true slot behind `slot`.
-__device__ __forceinline__ int jet_order(bool on, const float* maskf, int N, int slot, int wave, int lane, int* red,
-                                         short* order) {
-  if (!on) return slot;
-  const bool valid = slot < N;
-  const float m = valid ? maskf[slot] : 0.0f;
-  const unsigned real_b = (unsigned)__ballot(m != 0.0f), pad_b = (unsigned)__ballot(valid && m == 0.0f);   // lanes 0..31
-  __syncthreads();                                       // the readers of red's last use
-  if (lane == 0) red[wave] = __popc(real_b) | (__popc(pad_b) << 8);
-  __syncthreads();
-  int n_real = 0, real_before = 0, pad_before = 0;
-  for (int w = 0; w < FE_WAVES; ++w) {
-    const int f = red[w];
-    n_real += f & 255;
-    if (w < wave) { real_before += f & 255; pad_before += f >> 8; }
-  }
-  const unsigned below = (1u << (lane & 31)) - 1u;
-  const int pos = m != 0.0f ? real_before + __popc(real_b & below) : n_real + pad_before + __popc(pad_b & below);
-  if (valid && lane < 32) order[pos] = (short)slot;
-  __syncthreads();
-  return valid ? order[slot] : slot;
-}
-
-// Two jets share a CU, one wave of each on every SIMD, and most jets leave tiles idle: which SIMDs the working tiles sit
-// on decides whether the two jets' GEMMs meet on the same matrix pipes.  Tile t goes to SIMD t in the workgroup that
-// holds the first wave slot and to SIMD 3 - t in the other one (measured with two working tiles per jet: 62 ms -> 56 ms
-// for the S3 loop).  Returns the tile of this wave; the hardware wave order when the four waves do not sit on four SIMDs.
-__device__ __forceinline__ int steer_wave(bool on, int hw_wave, int lane, int* red) {
-  if (FE_WAVES != 4 || !on) return hw_wave;
-  const unsigned id = __builtin_amdgcn_s_getreg((5 << 11) | 4);      // HW_REG_HW_ID[5:0]: wave slot [3:0], SIMD [5:4]
-  if (lane == 0) red[hw_wave] = (int)id;
-  __syncthreads();
-  int seen = 0;
-  for (int w = 0; w < 4; ++w) seen |= 1 << ((red[w] >> 4) & 3);
-  const int flip = red[0] & 1, simd = (int)(id >> 4) & 3;
-  const int wave = seen == 0xF ? (flip ? 3 - simd : simd) : hw_wave;
-  __syncthreads();
-  return __builtin_amdgcn_readfirstlane(wave);
-}
-
 struct FusedArgs {
   const float* ctab;       // generation: (n_c_layers,128) time vectors W_t temb of the CURRENT grid point, or NULL
   const float* P;          // packed parameters
@@ -532,6 +468,8 @@ struct FusedArgs {
   const int32_t* counts;   // (B)
   int nb_branch1;          // EPiC layers of the discrete branch (nb_branch: the continuous one); they may differ
   int n_desc;              // descriptors behind D (cached in LDS by every workgroup)
+  int tiles;               // training kernels: bit 0 idle tiles of padded slots, bit 1 tile-to-SIMD steering (TilePlan)
+  const int32_t* jet_order;  // training kernels: (B) launch order of the jets (mmb_jet_schedule) or NULL
 };
 
 // ring depth of a width set: 4 fragments in flight where every GEMM of the model has a multiple of 4 steps (tiles of
@@ -567,8 +505,8 @@ __device__ __forceinline__ void embed_tile(f32x16& t, const float (&xp)[4], int 
 // One GELU head (multimodal_epic.py:188-189): Linear(cat[t, f_i, h_i]) -> GELU -> Linear.  in(IF<t>) yields the
 // 2*HBT input tiles; `o` receives the output tile; i0: descriptor of the first Linear.  Training slots:
 // pre-activation, hidden.
-template <class DM, int RD, bool CT, typename InFn, class TR>
-__device__ __forceinline__ void head(f32x16& o, InFn&& in, FCtx& c, int i0, int cslot,
+template <class DM, int RD, bool CT, typename InFn, class TR, class CX>
+__device__ __forceinline__ void head(f32x16& o, InFn&& in, CX& c, int i0, int cslot,
                                      int next_wx, WRing<RD>& ring, TR& tr) {
   constexpr int HBT = DM::HBT, HFT = DM::HFT;
   Lds& L = c.L;
@@ -594,7 +532,7 @@ __device__ __forceinline__ void head(f32x16& o, InFn&& in, FCtx& c, int i0, int 
   if (wave == 2) stage_commit(st, L.bvec, 32, lane);
   sync_pin();
   prio_gemm();
-  if (c.active) {
+  if constexpr (CX::active) {
   f32x16 h[HBT];
   acc_init<HBT>(h, c.m, L.cvec, L.dvec, half);
   mma_r<HFT, HBT, RD, true>(h, in, c.R, fld<F_WX>(dv.d[0]), fld<F_WX>(dv.d[1]), c.lane16, ring);
@@ -605,6 +543,8 @@ __device__ __forceinline__ void head(f32x16& o, InFn&& in, FCtx& c, int i0, int 
   acc_init<1>(oo, 0.0f, nullptr, L.bvec, half);
   mma_r<HBT, 1, RD, true>(oo, [&](auto fc) -> const f32x16& { return h[decltype(fc)::v]; }, c.R, fld<F_WX>(dv.d[1]), next_wx, c.lane16, ring);
   o = oo[0];
+  } else {
+    if constexpr (TR::on) tr.si += 2;
   }
 }
 
@@ -614,15 +554,15 @@ __device__ __forceinline__ void head(f32x16& o, InFn&& in, FCtx& c, int i0, int 
 // the last GEMM of a forward prefetches the first one of the next.
 // Training (TR = Train): slots in execution order -- per branch [projection 9, layers 8 each, output 1],
 // the concatenated global vector 1, fused encoder [layers 8 each, output 1], heads [pre, hidden] x 2.
-template <class DM, bool CT, class TR>
+template <class DM, bool CT, bool ACT = true, class TR>
 __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* S, const float (&xp)[4], int kp, float m,
                                             int which, f32x16& hc, f32x16& hd, int tid,
-                                            WRing<ring_depth_multi<DM>()>& ring, TR& tr, bool active = true) {
+                                            WRing<ring_depth_multi<DM>()>& ring, TR& tr) {
   constexpr int HBT = DM::HBT, HFT = DM::HFT, RD = ring_depth_multi<DM>();
   typedef Epic<HBT, DM::ET, DM::GB, RD, CT> EB;
   typedef Epic<HFT, DM::ET, DM::GF, RD, CT> EF;
   const int lane = tid & 63, half = lane >> 5;
-  FCtx c{A.P, weight_rsrc(A.P), L, m, tid, lane, tid >> 6, half, lane * 16, A.ctab, active};
+  FCtxT<ACT> c{A.P, weight_rsrc(A.P), L, m, tid, lane, tid >> 6, half, lane * 16, A.ctab};
   int li = 0, ci = 0;
   FE_PROF(L, PF_STEP);
   // S (LDS, HFT tiles) = cat[h1, h2]: fused-encoder input, its skip connection AND the heads' input
@@ -630,7 +570,7 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
   ffor<2>([&](auto bc) {
     constexpr int br = decltype(bc)::v;
     f32x16 x[HBT], out[HBT], tin;
-    if (active) embed_tile<DM, br>(tin, xp, kp, m, L, half);
+    if constexpr (ACT) embed_tile<DM, br>(tin, xp, kp, m, L, half);
     FE_PROF(L, PF_EMBED);
     const int nbb = br == 0 ? A.nb_branch : A.nb_branch1;
     // descriptors: projection 4, layers 4 each, output 1
@@ -639,7 +579,7 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
     if (tid < DM::GB) L.gskip[tid] = L.gcur[tid];        // read in the fourth interval of a layer: barriers in between
     // the skip tiles wait in the upper half of S (free until this branch's own output goes there, or -- branch 0 --
     // until branch 1's does): 16*HBT registers less across the layers
-    if (active) ffor<HBT>([&](auto t) { park_tile(S, HBT + decltype(t)::v, x[decltype(t)::v], tid); });
+    if constexpr (ACT) ffor<HBT>([&](auto t) { park_tile(S, HBT + decltype(t)::v, x[decltype(t)::v], tid); });
     for (int i = 0; i < nbb; ++i) {
       const int nx = desc_wx(L, i + 1 < nbb ? li + 4 + 2 : li + 4);
       EB::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, HBT + decltype(t)::v, tid); }, A.use_skip != 0, c, li, ci, nx,
@@ -650,7 +590,7 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
     if constexpr (br == 0) nx = desc_wx(L, li + 1);
     else nx = desc_wx(L, A.nb_fused_exec > 0 ? li + 1 + 2 : li + 1);
     EB::template output<HBT, DM::HB, (br == 0 || EF::CARRY)>(out, x, c, li, ci, nx, ring, tr);
-    if (active) ffor<HBT>([&](auto t) { park_tile(S, br * HBT + decltype(t)::v, out[decltype(t)::v], tid); });
+    if constexpr (ACT) ffor<HBT>([&](auto t) { park_tile(S, br * HBT + decltype(t)::v, out[decltype(t)::v], tid); });
     if (tid < DM::GB) L.gcat[br * DM::GB + tid] = L.gcur[tid];
   });
   // ---- fused encoder, no projection (K2: nb_fused_exec = constructed - 1).  gcat / gcur / gskip are written and read
@@ -658,7 +598,7 @@ __device__ __forceinline__ void forward_jet(const FusedArgs& A, Lds& L, float4* 
   if (tid < DM::GF) { L.gcur[tid] = L.gcat[tid]; L.gskip[tid] = L.gcat[tid]; }
   if constexpr (TR::on) tr.vec(L.gcat, DM::GF, tid);
   f32x16 x[HFT], f[HFT];
-  if (active) ffor<HFT>([&](auto t) { x[decltype(t)::v] = fetch_tile(S, decltype(t)::v, tid); });
+  if constexpr (ACT) ffor<HFT>([&](auto t) { x[decltype(t)::v] = fetch_tile(S, decltype(t)::v, tid); });
   for (int i = 0; i < A.nb_fused_exec; ++i) {
     const int nx = desc_wx(L, i + 1 < A.nb_fused_exec ? li + 4 + 2 : li + 4);
     EF::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, decltype(t)::v, tid); }, A.use_skip != 0, c, li, ci, nx, ring, tr);
@@ -772,36 +712,45 @@ fused_train_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64
                            float* __restrict__ head_d) {
   __shared__ Lds L;
   __shared__ float4 S[DM::HFT * 4 * FE_THREADS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  __shared__ short order_s[32 * FE_WAVES];
+  // tile t of a jet is the same particles in this kernel and in the reverse one (jet_order is a function of the mask);
+  // which hardware wave computes it is this kernel's own business (steer_wave)
+  const int lane = threadIdx.x & 63, wave = steer_wave((A.tiles & 2) != 0, threadIdx.x >> 6, lane, L.red);
+  const int tid = 64 * wave + lane, half = lane >> 5;
   load_constants<DM>(A, L, tid);
   __syncthreads();
   WRing<ring_depth_multi<DM>()> ring;
   ring_prime(ring, weight_rsrc(A.P), desc_wx(L, 0), lane * 16);
-  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+  for (int bi = blockIdx.x; bi < A.B; bi += gridDim.x) {
+    const int b = A.jet_order ? A.jet_order[bi] : bi;
     __syncthreads();
     if (tid < DM::ET) L.temb[tid] = temb[(int64_t)b * temb_stride + tid];
     if (tid == 0) L.cnt = (float)A.counts[b];
-    const int p = 32 * wave + (lane & 31);
-    const bool valid = p < A.N;
+    const int slot = 32 * wave + (lane & 31);
+    const bool valid = slot < A.N;
+    const int p = jet_order((A.tiles & 1) != 0, A.maskf + (int64_t)b * A.N, A.N, slot, wave, lane, L.red, order_s);
     const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
     const float m = valid ? A.maskf[gp] : 0.0f;
     float xp[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int d = 0; d < DM::DC; ++d) xp[d] = valid ? x[gp * DM::DC + d] : 0.0f;
     const int kp = valid ? (int)k[gp] : 0;
+    const TilePlan tp = plan_tiles((A.tiles & 1) != 0, false, m, valid, wave, lane, L.red);
     __syncthreads();
-    Train tr{slots, n_slots, 0, b, A.N, p, drop_p, seed, offset0};
+    Train tr{slots, n_slots, 0, b, A.N, p, drop_p, seed, offset0};      // rows and dropout keys by the true slot
     f32x16 hc, hd;
-    forward_jet<DM, false>(A, L, S, xp, kp, m, 2, hc, hd, tid, ring, tr);
+    if (tp.active) forward_jet<DM, false, true>(A, L, S, xp, kp, m, 2, hc, hd, tid, ring, tr);
+    else forward_jet<DM, false, false>(A, L, S, xp, kp, m, 2, hc, hd, tid, ring, tr);
+    // the heads of an idle tile: padded slots, which the masked losses multiply by zero -- zeros, not stale memory
     if (valid && half == 0) {
 #pragma unroll
-      for (int d = 0; d < DM::DC; ++d) head_c[gp * DM::DC + d] = hc[d];
+      for (int d = 0; d < DM::DC; ++d) head_c[gp * DM::DC + d] = tp.active ? hc[d] : 0.0f;
     }
     float lg[DM::V];
     gather_logits<DM>(hd, lg, lane);
     if (valid && half == 0) {
 #pragma unroll
-      for (int v = 0; v < DM::V; ++v) head_d[gp * DM::V + v] = lg[v];
+      for (int v = 0; v < DM::V; ++v) head_d[gp * DM::V + v] = tp.active ? lg[v] : 0.0f;
     }
   }
 }
@@ -895,7 +844,7 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
 #pragma unroll
     for (int d = 0; d < DM::DC; ++d) xp[d] = valid ? x[gp * DM::DC + d] : 0.0f;
     int kp = valid ? (int)k[gp] : 0;
-    const TilePlan tp = plan_tiles((Gn.tiles & 1) != 0, m, valid, wave, lane, L.red);
+    const TilePlan tp = plan_tiles((Gn.tiles & 1) != 0, true, m, valid, wave, lane, L.red);
     for (int s = 0; s < Gn.steps; ++s) {
       __syncthreads();
       if (tid < DM::ET) L.temb[tid] = Gn.temb_steps[(int64_t)s * DM::ET + tid];
@@ -918,7 +867,8 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
       // Euler step on the drift head (solvers.py:21-25); padded slots move too (K3)
       park();
       NoTrain nt;
-      forward_jet<DM, true>(A, L, S, xp, kp, m, 0, hc, hd, tid, ring, nt, tp.active);
+      if (tp.active) forward_jet<DM, true, true>(A, L, S, xp, kp, m, 0, hc, hd, tid, ring, nt);
+      else forward_jet<DM, true, false>(A, L, S, xp, kp, m, 0, hc, hd, tid, ring, nt);
       unpark();
       {
         float v[3] = {hc[0], hc[1], hc[2]};
@@ -958,7 +908,8 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
       __syncthreads();
       // tau-leap on the logits head, which sees the UPDATED x at the same t (solvers.py:59-81)
       park();
-      forward_jet<DM, true>(A, L, S, xp, kp, m, 1, hc, hd, tid, ring, nt, tp.active);
+      if (tp.active) forward_jet<DM, true, true>(A, L, S, xp, kp, m, 1, hc, hd, tid, ring, nt);
+      else forward_jet<DM, true, false>(A, L, S, xp, kp, m, 1, hc, hd, tid, ring, nt);
       unpark();
       float r[V];
       gather_logits<DM>(hd, r, lane);
@@ -990,18 +941,17 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
 // layer emits the V logits directly (no heads).
 
 // Training (TR = Train) slots: projection 9, layers 8 each (the V logits of the output layer go to the caller).
-template <class DM, bool CT, class TR>
+template <class DM, bool CT, bool ACT = true, class TR>
 __device__ __forceinline__ void forward_uni(const FusedArgs& A, Lds& L, float4* S, const float* tab, int kp, float m,
-                                            f32x16& hd, int tid, WRing<ring_depth_uni<DM>()>& ring, TR& nt,
-                                            bool active = true) {
+                                            f32x16& hd, int tid, WRing<ring_depth_uni<DM>()>& ring, TR& nt) {
   constexpr int HT = DM::HT, RD = ring_depth_uni<DM>();
   typedef Epic<HT, DM::ET, DM::G, RD, CT> E;
   const int lane = tid & 63, half = lane >> 5;
-  FCtx c{A.P, weight_rsrc(A.P), L, m, tid, lane, tid >> 6, half, lane * 16, A.ctab, active};
+  FCtxT<ACT> c{A.P, weight_rsrc(A.P), L, m, tid, lane, tid >> 6, half, lane * 16, A.ctab};
   int li = 0, ci = 0;
   FE_PROF(L, PF_STEP);
   f32x16 td[DM::EDT];
-  if (active) ffor<DM::EDT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+  if constexpr (ACT) ffor<DM::EDT>([&](auto tc) { constexpr int t = decltype(tc)::v;
     ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
       const float4 e = *reinterpret_cast<const float4*>(tab + kp * DM::EDP + 32 * t + 8 * q + 4 * half);
       td[t][4 * q + 0] = truncf(e.x * m); td[t][4 * q + 1] = truncf(e.y * m);      // quirk Q1
@@ -1013,7 +963,7 @@ __device__ __forceinline__ void forward_uni(const FusedArgs& A, Lds& L, float4* 
   E::template project<DM::EDT>(x, [&](auto fc) -> const f32x16& { return td[decltype(fc)::v]; }, c, li, ci, wx_after_proj,
                                ring, nt);
   if (tid < DM::G) L.gskip[tid] = L.gcur[tid];
-  if (active) ffor<HT>([&](auto t) { park_tile(S, decltype(t)::v, x[decltype(t)::v], tid); });
+  if constexpr (ACT) ffor<HT>([&](auto t) { park_tile(S, decltype(t)::v, x[decltype(t)::v], tid); });
   for (int i = 0; i < nb; ++i) {
     const int nx = desc_wx(L, i + 1 < nb ? li + 4 + 2 : li + 4);
     E::layer(x, [&](auto t) -> f32x16 { return fetch_tile(S, decltype(t)::v, tid); }, A.use_skip != 0, c, li, ci, nx, ring, nt);
@@ -1091,30 +1041,36 @@ fused_uni_train_forward_kernel(FusedArgs A, const int64_t* __restrict__ k, const
   __shared__ Lds L;
   __shared__ float4 S[DM::HT * 4 * FE_THREADS];
   __shared__ __attribute__((aligned(16))) float tab[DM::V * DM::EDP];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  __shared__ short order_s[32 * FE_WAVES];
+  const int lane = threadIdx.x & 63, wave = steer_wave((A.tiles & 2) != 0, threadIdx.x >> 6, lane, L.red);
+  const int tid = 64 * wave + lane, half = lane >> 5;
   load_table_uni<DM>(A, tab, tid);
   load_desc(A, L, tid);
   __syncthreads();
   WRing<ring_depth_uni<DM>()> ring;
   ring_prime(ring, weight_rsrc(A.P), desc_wx(L, 0), lane * 16);
-  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+  for (int bi = blockIdx.x; bi < A.B; bi += gridDim.x) {
+    const int b = A.jet_order ? A.jet_order[bi] : bi;
     __syncthreads();
     if (tid < DM::ET) L.temb[tid] = temb[(int64_t)b * temb_stride + tid];
     if (tid == 0) L.cnt = (float)A.counts[b];
-    const int p = 32 * wave + (lane & 31);
-    const bool valid = p < A.N;
+    const int slot = 32 * wave + (lane & 31);
+    const bool valid = slot < A.N;
+    const int p = jet_order((A.tiles & 1) != 0, A.maskf + (int64_t)b * A.N, A.N, slot, wave, lane, L.red, order_s);
     const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
     const float m = valid ? A.maskf[gp] : 0.0f;
     const int kp = valid ? (int)k[gp] : 0;
+    const TilePlan tp = plan_tiles((A.tiles & 1) != 0, false, m, valid, wave, lane, L.red);
     __syncthreads();
-    Train tr{slots, n_slots, 0, b, A.N, p, drop_p, seed, offset0};
+    Train tr{slots, n_slots, 0, b, A.N, p, drop_p, seed, offset0};      // rows and dropout keys by the true slot
     f32x16 hd;
-    forward_uni<DM, false>(A, L, S, tab, kp, m, hd, tid, ring, tr);
+    if (tp.active) forward_uni<DM, false, true>(A, L, S, tab, kp, m, hd, tid, ring, tr);
+    else forward_uni<DM, false, false>(A, L, S, tab, kp, m, hd, tid, ring, tr);
     float lg[8];
     gather8(hd, lg, lane);
     if (valid && half == 0) {
 #pragma unroll
-      for (int v = 0; v < 8; ++v) head_d[gp * 8 + v] = lg[v];
+      for (int v = 0; v < 8; ++v) head_d[gp * 8 + v] = tp.active ? lg[v] : 0.0f;      // (idle tile: padded slots, masked loss)
     }
   }
 }
@@ -1148,7 +1104,7 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
     const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
     const float m = valid ? A.maskf[gp] : 0.0f;
     int kp = valid ? (int)k[gp] : 0;
-    const TilePlan tp = plan_tiles((Gn.tiles & 1) != 0, m, valid, wave, lane, L.red);
+    const TilePlan tp = plan_tiles((Gn.tiles & 1) != 0, true, m, valid, wave, lane, L.red);
     for (int s = 0; s < Gn.steps; ++s) {
       __syncthreads();
       if (tid < DM::ET) L.temb[tid] = Gn.temb_steps[(int64_t)s * DM::ET + tid];
@@ -1156,7 +1112,8 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
       A.ctab = Gn.ctab_steps + (int64_t)s * Gn.n_ctab * 128;
       f32x16 hd;
       NoTrain nt;
-      forward_uni<DM, true>(A, L, S, tab, kp, m, hd, tid, ring, nt, tp.active);
+      if (tp.active) forward_uni<DM, true, true>(A, L, S, tab, kp, m, hd, tid, ring, nt);
+      else forward_uni<DM, true, false>(A, L, S, tab, kp, m, hd, tid, ring, nt);
       float r[8];
       gather8(hd, r, lane);
       if (tp.idle_any) {
@@ -1186,6 +1143,12 @@ static int stagger_cycles(int dflt) {
 // MMB_GEN_TILES=<bits> (developer switch; default 3): bit 0 idle tiles of padded slots, bit 1 tile-to-SIMD steering
 static int gen_tiles() {
   const char* e = getenv("MMB_GEN_TILES");
+  return e ? atoi(e) : 3;
+}
+// MMB_TRAIN_TILES=<bits> (developer switch; default 3): the same two bits for the training kernels (forward and
+// reverse read it per call: both must run under the same setting, they share the tile order)
+static int train_tiles() {
+  const char* e = getenv("MMB_TRAIN_TILES");
   return e ? atoi(e) : 3;
 }
 static int check_fused(const char* name, int B, int N, const void* P, const void* D, const void* maskf,
@@ -1220,10 +1183,11 @@ extern "C" int mmb_fused_epic_generate_w5(int, int, int, const float*, const int
                                           const float*, const int32_t*, void*);
 extern "C" int mmb_fused_epic_train_forward_w5(int, int, int, const float*, const int32_t*, int, int, int, int, int, int, int,
                                                const float*, const int32_t*, const float*, const int64_t*, const float*,
-                                               int64_t, const void*, int, float, uint64_t, uint64_t, float*, float*, void*);
+                                               int64_t, const void*, int, float, uint64_t, uint64_t, float*, float*,
+                                               const int32_t*, void*);
 extern "C" int mmb_fused_uni_train_forward_w5(int, int, int, const float*, const int32_t*, int, int, int, const float*,
                                               const int32_t*, const int64_t*, const float*, int64_t, const void*, int, float,
-                                              uint64_t, uint64_t, float*, void*);
+                                              uint64_t, uint64_t, float*, const int32_t*, void*);
 #endif
 
 // variant: 0 = S3 dims (Et32 Ec16 Ed16 H64/64/128 G16/16/32), 1 = "mid" dims (Et16 Ec8 Ed8 H32/32/64 G8/8/16)
@@ -1264,11 +1228,12 @@ extern "C" int mmb_fused_epic_train_forward(int variant, int B, int N, const flo
                                             int off_table, const float* maskf, const int32_t* counts, const float* x,
                                             const int64_t* k, const float* temb, int64_t temb_stride,
                                             const void* slots, int n_slots, float drop_p, uint64_t seed,
-                                            uint64_t offset0, float* head_c, float* head_d, void* stream) {
+                                            uint64_t offset0, float* head_c, float* head_d, const int32_t* jet_order,
+                                            void* stream) {
 #if MMB_FE_WAVES == 4
   if (N > 128) return mmb_fused_epic_train_forward_w5(variant, B, N, packed, desc, nb_branch, nb_branch1, nb_fused_exec, use_skip,
                                                       off_cw, off_cb, off_table, maskf, counts, x, k, temb, temb_stride, slots,
-                                                      n_slots, drop_p, seed, offset0, head_c, head_d, stream);
+                                                      n_slots, drop_p, seed, offset0, head_c, head_d, jet_order, stream);
 #endif
   int rc = check_fused("mmb_fused_epic_train_forward", B, N, packed, desc, maskf, counts, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec));
   if (rc) return rc;
@@ -1279,7 +1244,8 @@ extern "C" int mmb_fused_epic_train_forward(int variant, int B, int N, const flo
   MMB_REQUIRE(n_slots == expect, "mmb_fused_epic_train_forward: %d save slots given, the architecture has %d", n_slots,
               expect);
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
-              off_table, B, N, maskf, counts, nb_branch1, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec)};
+              off_table, B, N, maskf, counts, nb_branch1, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec), train_tiles(),
+              jet_order};
   const SaveSlot* tab = reinterpret_cast<const SaveSlot*>(slots);
   const int grid = B < 4096 ? B : 4096;
   switch (variant) {
@@ -1328,10 +1294,12 @@ extern "C" int mmb_fused_uni_train_forward(int variant, int B, int N, const floa
                                            int num_blocks, int use_skip, int off_table, const float* maskf,
                                            const int32_t* counts, const int64_t* k, const float* temb,
                                            int64_t temb_stride, const void* slots, int n_slots, float drop_p,
-                                           uint64_t seed, uint64_t offset0, float* head_d, void* stream) {
+                                           uint64_t seed, uint64_t offset0, float* head_d, const int32_t* jet_order,
+                                           void* stream) {
 #if MMB_FE_WAVES == 4
   if (N > 128) return mmb_fused_uni_train_forward_w5(variant, B, N, packed, desc, num_blocks, use_skip, off_table, maskf, counts,
-                                                     k, temb, temb_stride, slots, n_slots, drop_p, seed, offset0, head_d, stream);
+                                                     k, temb, temb_stride, slots, n_slots, drop_p, seed, offset0, head_d, jet_order,
+                                                     stream);
 #endif
   int rc = check_fused("mmb_fused_uni_train_forward", B, N, packed, desc, maskf, counts, n_desc_uni(num_blocks));
   if (rc) return rc;
@@ -1342,7 +1310,7 @@ extern "C" int mmb_fused_uni_train_forward(int variant, int B, int N, const floa
   MMB_REQUIRE(n_slots == expect, "mmb_fused_uni_train_forward: %d save slots given, the architecture has %d", n_slots,
               expect);
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), num_blocks, 0, use_skip, 0, 0, off_table, B, N,
-              maskf, counts, 0, n_desc_uni(num_blocks)};
+              maskf, counts, 0, n_desc_uni(num_blocks), train_tiles(), jet_order};
   const SaveSlot* tab = reinterpret_cast<const SaveSlot*>(slots);
   const int grid = B < 4096 ? B : 4096;
   switch (variant) {
@@ -1392,10 +1360,23 @@ extern "C" int mmb_fused_uni_generate(int variant, int B, int N, const float* pa
 #if MMB_FE_WAVES == 4
 // ---- launch order of the jets of a generation call ------------------------------------------------
 // A jet costs what its working tiles cost (TilePlan), and a call has few jets per workgroup slot (1024 jets on 512
-// slots): in their natural order the last slots to finish hold two long jets while the rest of the chip idles.  Longest
-// first: the jets sorted by particle count, descending (a counting sort in one workgroup; jets of one count in any
-// order -- a jet's result does not depend on the workgroup that computes it).
-__global__ void __launch_bounds__(1024) jet_schedule_kernel(const int32_t* __restrict__ counts, int B, int32_t* __restrict__ order) {
+// slots).  Two things decide the time of the call: which jets share a CU -- the working tiles of two jets run side by
+// side only while together they fit the four SIMDs (steer_wave) -- and how long the last slots run.  The jets are sorted
+// by particle count (a counting sort in one workgroup; jets of one count in any order: a jet's result does not depend on
+// the workgroup that computes it) and dealt out in rounds of `chunk` = one workgroup per CU: the heaviest chunk, then
+// the lightest chunk (workgroups i and i + chunk share CU i in the first two rounds: heaviest with lightest), the
+// second heaviest, the second lightest, ...; what is left in the middle follows, heaviest first.  chunk = 0: plain
+// longest first.
+__device__ __forceinline__ int schedule_pos(int r, int B, int chunk) {
+  if (chunk <= 0) return r;
+  const int cp = (B / (2 * chunk)) * chunk;              // jets on either end that form whole pairs of rounds
+  if (r < cp) return 2 * (r / chunk) * chunk + r % chunk;
+  const int rl = B - 1 - r;
+  if (rl < cp) return (2 * (rl / chunk) + 1) * chunk + rl % chunk;
+  return 2 * cp + (r - cp);
+}
+__global__ void __launch_bounds__(1024) jet_schedule_kernel(const int32_t* __restrict__ counts, int B, int chunk,
+                                                           int32_t* __restrict__ order) {
   __shared__ int bin[256];
   const int tid = threadIdx.x;
   if (tid < 256) bin[tid] = 0;
@@ -1407,12 +1388,20 @@ __global__ void __launch_bounds__(1024) jet_schedule_kernel(const int32_t* __res
     for (int c = 0; c < 256; ++c) { const int n = bin[c]; bin[c] = run; run += n; }
   }
   __syncthreads();
-  for (int i = tid; i < B; i += 1024) order[atomicAdd(&bin[255 - min(max(counts[i], 0), 255)], 1)] = i;
+  for (int i = tid; i < B; i += 1024)
+    order[schedule_pos(atomicAdd(&bin[255 - min(max(counts[i], 0), 255)], 1), B, chunk)] = i;
 }
 
 extern "C" int mmb_jet_schedule(int B, const int32_t* counts, int32_t* order, void* stream) {
   MMB_REQUIRE(B > 0 && counts && order, "mmb_jet_schedule: needs B > 0 and two buffers of B int32 (got B=%d)", B);
-  hipLaunchKernelGGL(jet_schedule_kernel, dim3(1), dim3(1024), 0, as_stream(stream), counts, B, order);
+  int chunk = 0;
+  if (const char* e = getenv("MMB_GEN_PAIR")) {          // developer switch: the round size (0: plain longest first)
+    chunk = atoi(e);
+  } else {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&chunk, hipDeviceAttributeMultiprocessorCount, dev);
+  }
+  hipLaunchKernelGGL(jet_schedule_kernel, dim3(1), dim3(1024), 0, as_stream(stream), counts, B, chunk, order);
   return check_launch("mmb_jet_schedule");
 }
 

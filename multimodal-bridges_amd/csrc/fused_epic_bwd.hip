@@ -50,6 +50,8 @@ struct BwdArgs {
   float drop_p;
   uint64_t seed, offset0;
   int nb_branch1;
+  int tiles;               // bit 0 idle tiles of padded slots, bit 1 tile-to-SIMD steering: as the forward ran (TilePlan)
+  const int32_t* jet_order;  // (B) launch order of the jets (mmb_jet_schedule) or NULL
 };
 
 __device__ __forceinline__ float gelu_grad(float z) {
@@ -84,9 +86,14 @@ __device__ __forceinline__ void mma_go(f32x16 (&acc)[OT], TileFn&& tile, const f
 
 // s = column sums of the dZ tiles over the jet's particles -> LB.svec and row b of the next slot
 template <int HT>
-__device__ __forceinline__ void colsum(const f32x16 (&dz)[HT], LdsB& LB, Slots& sl, int tid, int W = 32 * HT) {
+__device__ __forceinline__ void colsum(const f32x16 (&dz)[HT], LdsB& LB, Slots& sl, int tid, bool act, int W = 32 * HT) {
   const int lane = tid & 63, wave = tid >> 6;
-  pool_partials<HT>(dz, 1.0f, LB.partial, wave, lane);
+  if (act) {
+    pool_partials<HT>(dz, 1.0f, LB.partial, wave, lane);
+  } else {                                                 // an idle tile: zero rows
+    LB.partial[wave * 128 + lane] = 0.0f;
+    LB.partial[wave * 128 + 64 + lane] = 0.0f;
+  }
   __syncthreads();
   float* dst = sl.row(W);                                // W: true width of the layer (the slot's row length)
   if (tid < 32 * HT) {
@@ -112,10 +119,10 @@ struct EpicB {
   static constexpr int H = 32 * HT;
 
   // gradient of the masked mean/sum pooling (epic.py:100-107) added to dx; LB.dpool holds d pooled (2H)
-  static __device__ __forceinline__ void pool_bwd(f32x16 (&dx)[HT], LdsB& LB, float m, int tid, int half) {
+  static __device__ __forceinline__ void pool_bwd(f32x16 (&dx)[HT], LdsB& LB, float m, int tid, int half, bool act) {
     if (tid < H) LB.cpool[tid] = LB.dpool[tid] / LB.cnt + 0.01f * LB.dpool[H + tid];
     __syncthreads();
-    add_mc<HT>(dx, m, LB.cpool, half);
+    if (act) add_mc<HT>(dx, m, LB.cpool, half);
   }
 
   // output layer  out = W [m temb, x, g] + b.  Slots: S_out.  In: dout (its dZ, already in HBM).
@@ -123,14 +130,14 @@ struct EpicB {
   template <int OTO>
   static __device__ __forceinline__ void output_bwd(f32x16 (&dx)[HT], const f32x16 (&dout)[OTO], const BDesc o,
                                                     const float* __restrict__ P, const float* add, LdsB& LB, Slots& sl,
-                                                    int tid, int ow = 32 * OTO) {
+                                                    int tid, bool act, int ow = 32 * OTO) {
     const int lane = tid & 63;
-    colsum<OTO>(dout, LB, sl, tid, ow);
+    colsum<OTO>(dout, LB, sl, tid, act, ow);
     auto sv = [&](int k) { return LB.svec[k]; };
     WaveMV<32 * OTO, ET>::template run<MMB_ACT_NONE>(P + o.b, nullptr, sv, LB.dtemb, LB.dtemb, tid);
     WaveMV<32 * OTO, G>::template run<MMB_ACT_NONE>(P + o.c, nullptr, sv, LB.dg, add, tid);
     zero_tiles<HT>(dx);
-    mma_go<OTO, HT>(dx, [&](auto fc) -> const f32x16& { return dout[decltype(fc)::v]; }, P, o.a, lane);
+    if (act) mma_go<OTO, HT>(dx, [&](auto fc) -> const f32x16& { return dout[decltype(fc)::v]; }, P, o.a, lane);
   }
 
   // EPiCLayer + encoder-level skip.  In: dx = d l_out, LB.dg = d g_out.  Out: dx = d x_local, LB.dg = d x_global;
@@ -138,18 +145,20 @@ struct EpicB {
   // Slots: sign bits of y1, dz_l2, sign bits of lh's pre-activation, dz_l1, S_l1, g_new, dz_g2, gh, dz_g1.
   static __device__ __forceinline__ void layer_bwd(f32x16 (&dx)[HT], const BDesc* __restrict__ D, const float* __restrict__ P,
                                                    bool use_skip, LdsB& LB, float4* S, Slots& sl, float m, int tid,
-                                                   float drop_p, uint64_t seed, uint64_t off_g, uint64_t off_l) {
+                                                   float drop_p, uint64_t seed, uint64_t off_g, uint64_t off_l, bool act) {
     const int lane = tid & 63, half = lane >> 5;
     const BDesc g1 = D[0], g2 = D[1], l1 = D[2], l2 = D[3];
     const bool dr = drop_p > 0.0f;
+    // An idle tile (padded slots only: every gradient row is exactly zero) keeps the slot walk, the barriers and its
+    // share of the per-jet matvecs, stores its zero dZ rows for the weight-gradient kernels and skips the rest.
     // ---- l_out = drop(lrelu(y1)) + skip ;  y1 = x + W2 lh + b2
     const uint64_t sgn_y1 = sl.bits(tid);
     const Rows r_dz2 = sl.rows();
     const uint64_t sgn_lh = sl.bits(tid);                  // (both sign words before any store of this layer)
     const Rows r_dz1 = sl.rows();
     uint64_t keep = 0;
-    if (dr) keep = dropout_keep_bits<HT>(drop_p, seed, off_l, (uint64_t)sl.b * sl.N + sl.p, half);
-    ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+    if (dr && act) keep = dropout_keep_bits<HT>(drop_p, seed, off_l, (uint64_t)sl.b * sl.N + sl.p, half);
+    if (act) ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
       if (use_skip) {
         f32x16 sk = fetch_tile(S, t, tid);
         ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; sk[r] += dx[t][r]; });
@@ -165,15 +174,15 @@ struct EpicB {
     // loads and stores in one order, so a store issued before a GEMM holds up every weight fragment of that GEMM
     f32x16 dlh[HT];
     zero_tiles<HT>(dlh);
-    mma_go<HT, HT>(dlh, [&](auto fc) -> const f32x16& { return dx[decltype(fc)::v]; }, P, l2.a, lane);
+    if (act) mma_go<HT, HT>(dlh, [&](auto fc) -> const f32x16& { return dx[decltype(fc)::v]; }, P, l2.a, lane);
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v; store_tile(r_dz2, t, dx[t]); });
-    ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
+    if (act) ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
       const uint32_t sw = (uint32_t)(sgn_lh >> (32 * (t >> 1)));
       ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v;
         if (!((sw >> (16 * (t & 1) + r)) & 1u)) dlh[t][r] *= 0.01f; }); });
-    colsum<HT>(dlh, LB, sl, tid);
+    colsum<HT>(dlh, LB, sl, tid, act);
     // d x = d y1 (residual) + Wx1^T d z1
-    mma_go<HT, HT>(dx, [&](auto fc) -> const f32x16& { return dlh[decltype(fc)::v]; }, P, l1.a, lane);
+    if (act) mma_go<HT, HT>(dx, [&](auto fc) -> const f32x16& { return dlh[decltype(fc)::v]; }, P, l1.a, lane);
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v; store_tile(r_dz1, t, dlh[t]); });
     auto sv = [&](int k) { return LB.svec[k]; };
     WaveMV<H, ET>::template run<MMB_ACT_NONE>(P + l1.b, nullptr, sv, LB.dtemb, LB.dtemb, tid);
@@ -207,7 +216,7 @@ struct EpicB {
     __syncthreads();
     matvec<MMB_ACT_NONE, H, 2 * H>(P + g1.a, nullptr, LB.dzg, LB.dpool, nullptr, tid);
     matvec<MMB_ACT_NONE, H, G>(P + g1.b, nullptr, LB.dzg, LB.dg, LB.dg, tid);
-    pool_bwd(dx, LB, m, tid, half);
+    pool_bwd(dx, LB, m, tid, half, act);
     __syncthreads();
   }
 
@@ -215,10 +224,11 @@ struct EpicB {
   // pre_p2, dz_p2, pre_p0, dz_p0, S_p0, [d_in (EIN wide) when EIN > 0].
   template <int EIN>
   static __device__ __forceinline__ void project_bwd(f32x16 (&dx)[HT], const BDesc* __restrict__ D, const float* __restrict__ P,
-                                                     bool use_skip, LdsB& LB, float4* S, Slots& sl, float m, int tid) {
+                                                     bool use_skip, LdsB& LB, float4* S, Slots& sl, float m, int tid,
+                                                     bool act) {
     const int lane = tid & 63, half = lane >> 5;
     const BDesc p0 = D[0], p2 = D[1], q0 = D[2], q2 = D[3];
-    if (use_skip) {                                      // the projection's outputs ARE the skip tensors
+    if (use_skip && act) {                               // the projection's outputs ARE the skip tensors
       ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
         const f32x16 sk = fetch_tile(S, t, tid);
         ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; dx[t][r] += sk[r]; }); });
@@ -242,28 +252,32 @@ struct EpicB {
     __syncthreads();
     matvec<MMB_ACT_NONE, H, 2 * H>(P + q0.a, nullptr, LB.dzg, LB.dpool, nullptr, tid);
     matvec<MMB_ACT_NONE, H, ET>(P + q0.b, nullptr, LB.dzg, LB.dtemb, LB.dtemb, tid);    // context = time embedding
-    pool_bwd(dx, LB, m, tid, half);
+    pool_bwd(dx, LB, m, tid, half, act);
     // ---- local MLP: x = gelu(z2), z2 = W2 h + b ; h = gelu(z0), z0 = W0 [m temb, x_in] + b
     const Rows r_pre2 = sl.rows(), r_dz2 = sl.rows();
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
-      const f32x16 a = load_tile(r_pre2, t);
-      ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; dx[t][r] *= gelu_grad(a[r]); });
+      if (act) {                                         // (an idle tile's saved rows were never written: 0 * stale)
+        const f32x16 a = load_tile(r_pre2, t);
+        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; dx[t][r] *= gelu_grad(a[r]); });
+      }
       store_tile(r_dz2, t, dx[t]); });
     f32x16 dh[HT];
     zero_tiles<HT>(dh);
-    mma_go<HT, HT>(dh, [&](auto fc) -> const f32x16& { return dx[decltype(fc)::v]; }, P, p2.a, lane);
+    if (act) mma_go<HT, HT>(dh, [&](auto fc) -> const f32x16& { return dx[decltype(fc)::v]; }, P, p2.a, lane);
     const Rows r_pre0 = sl.rows(), r_dz0 = sl.rows();
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
-      const f32x16 a = load_tile(r_pre0, t);
-      ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; dh[t][r] *= gelu_grad(a[r]); });
+      if (act) {
+        const f32x16 a = load_tile(r_pre0, t);
+        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; dh[t][r] *= gelu_grad(a[r]); });
+      }
       store_tile(r_dz0, t, dh[t]); });
-    colsum<HT>(dh, LB, sl, tid);
+    colsum<HT>(dh, LB, sl, tid, act);
     auto sv = [&](int k) { return LB.svec[k]; };
     WaveMV<H, ET>::template run<MMB_ACT_NONE>(P + p0.b, nullptr, sv, LB.dtemb, LB.dtemb, tid);
     if constexpr (EIN > 0) {
       f32x16 din[1];
       zero_tiles<1>(din);
-      mma_go<HT, 1>(din, [&](auto fc) -> const f32x16& { return dh[decltype(fc)::v]; }, P, p0.a, lane);
+      if (act) mma_go<HT, 1>(din, [&](auto fc) -> const f32x16& { return dh[decltype(fc)::v]; }, P, p0.a, lane);
       const Rows r = sl.rows();                          // (rows, EIN): only the column groups below EIN exist
       ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
         if (8 * q + 4 * half < EIN) {
@@ -283,17 +297,25 @@ __global__ void __launch_bounds__(FE_THREADS, FE_WAVES == 4 ? 2 : 1)
 fused_train_backward_kernel(BwdArgs A) {
   __shared__ LdsB LB;
   __shared__ float4 S[DM::HFT * 4 * FE_THREADS];
+  __shared__ int red_s[8];
+  __shared__ short order_s[32 * FE_WAVES];
   constexpr int HBT = DM::HBT, HFT = DM::HFT, HB = DM::HB, GB = DM::GB, GF = DM::GF, ET = DM::ET;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  // tile t of a jet holds the particles it held in the forward (jet_order: a function of the mask; the sign words are
+  // indexed by tile and lane); the hardware wave that computes it is chosen here (steer_wave)
+  const int lane = threadIdx.x & 63, wave = steer_wave((A.tiles & 2) != 0, threadIdx.x >> 6, lane, red_s);
+  const int tid = 64 * wave + lane, half = lane >> 5;
   const int nb0 = A.nb_branch, nb1 = A.nb_branch1, nbf = A.nb_fused_exec;
   const bool use_skip = A.use_skip != 0;
   const int base_f = 2 * 5 + 4 * (nb0 + nb1), base_h = base_f + 4 * nbf + 1;
-  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+  for (int bi = blockIdx.x; bi < A.B; bi += gridDim.x) {
+    const int b = A.jet_order ? A.jet_order[bi] : bi;
     __syncthreads();
-    const int p = 32 * wave + (lane & 31);
-    const bool valid = p < A.N;
+    const int slot = 32 * wave + (lane & 31);
+    const bool valid = slot < A.N;
+    const int p = jet_order((A.tiles & 1) != 0, A.maskf + (int64_t)b * A.N, A.N, slot, wave, lane, red_s, order_s);
     const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
     const float m = valid ? A.maskf[gp] : 0.0f;
+    const bool act = plan_tiles((A.tiles & 1) != 0, false, m, valid, wave, lane, red_s).active;
     if (tid == 0) LB.cnt = (float)A.counts[b];
     if (tid < 128) LB.dtemb[tid] = 0.0f;
     __syncthreads();
@@ -307,31 +329,33 @@ fused_train_backward_kernel(BwdArgs A) {
       f32x16 dzo[1];
       zero_tiles<1>(dzo);
       if constexpr (hi == 0) {
-        if (valid && half == 0 && (gp + 1) * sd.ld <= sd.n) {
+        if (act && valid && half == 0 && (gp + 1) * sd.ld <= sd.n) {
 #pragma unroll
           for (int d = 0; d < DM::DC; ++d) dzo[0][d] = sd.p[gp * sd.ld + d];
         }
       } else {
         static_assert(DM::V == 8, "fused path is instantiated for vocab_size 8");
-        if (valid && (gp + 1) * sd.ld <= sd.n) {
+        if (act && valid && (gp + 1) * sd.ld <= sd.n) {
           const float4 v = *reinterpret_cast<const float4*>(sd.p + gp * sd.ld + 4 * half);
           dzo[0][0] = v.x; dzo[0][1] = v.y; dzo[0][2] = v.z; dzo[0][3] = v.w;
         }
       }
       f32x16 dh[HBT];
       zero_tiles<HBT>(dh);
-      mma_go<1, HBT>(dh, [&](auto) -> const f32x16& { return dzo[0]; }, A.P, h2.a, lane);
+      if (act) mma_go<1, HBT>(dh, [&](auto) -> const f32x16& { return dzo[0]; }, A.P, h2.a, lane);
       const Rows r_pre = sl.rows(), r_dz = sl.rows();
       ffor<HBT>([&](auto tc) { constexpr int t = decltype(tc)::v;
-        const f32x16 a = load_tile(r_pre, t);
-        ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; dh[t][r] *= gelu_grad(a[r]); });
+        if (act) {                                       // (an idle tile's saved rows were never written: 0 * stale)
+          const f32x16 a = load_tile(r_pre, t);
+          ffor<16>([&](auto rc) { constexpr int r = decltype(rc)::v; dh[t][r] *= gelu_grad(a[r]); });
+        }
         store_tile(r_dz, t, dh[t]); });
-      colsum<HBT>(dh, LB, sl, tid);
+      colsum<HBT>(dh, LB, sl, tid, act);
       WaveMV<HB, ET>::template run<MMB_ACT_NONE>(A.P + h0.b, nullptr, [&](int k) { return LB.svec[k]; }, LB.dtemb,
                                                  LB.dtemb, tid);
       f32x16 din[HFT];
       zero_tiles<HFT>(din);
-      mma_go<HBT, HFT>(din, [&](auto fc) -> const f32x16& { return dh[decltype(fc)::v]; }, A.P, h0.a, lane);
+      if (act) mma_go<HBT, HFT>(din, [&](auto fc) -> const f32x16& { return dh[decltype(fc)::v]; }, A.P, h0.a, lane);
       const Rows r_df = sl.rows_of(s_df, hi * HB), r_dhb = sl.rows_of(s_dhb, hi * HB);
       ffor<HBT>([&](auto tc) { constexpr int t = decltype(tc)::v;
         store_tile(r_df, t, din[t]);
@@ -344,7 +368,7 @@ fused_train_backward_kernel(BwdArgs A) {
         f32x16 dout[HFT];
         const Rows r = sl.rows_of(s_df);
         ffor<HFT>([&](auto tc) { constexpr int t = decltype(tc)::v; dout[t] = load_tile(r, t); });
-        EpicB<HFT, ET, GF>::template output_bwd<HFT>(dx, dout, A.D[base_f + 4 * nbf], A.P, nullptr, LB, sl, tid);
+        EpicB<HFT, ET, GF>::template output_bwd<HFT>(dx, dout, A.D[base_f + 4 * nbf], A.P, nullptr, LB, sl, tid, act);
       }
       if (use_skip) {
         f32x16 z;
@@ -356,7 +380,7 @@ fused_train_backward_kernel(BwdArgs A) {
       for (int i = nbf - 1; i >= 0; --i) {
         const uint64_t j = (uint64_t)(nb0 + nb1 + i);
         EpicB<HFT, ET, GF>::layer_bwd(dx, A.D + base_f + 4 * i, A.P, use_skip, LB, S, sl, m, tid, A.drop_p, A.seed,
-                                      A.offset0 + 2 * j + 1, A.offset0 + 2 * j + 2);
+                                      A.offset0 + 2 * j + 1, A.offset0 + 2 * j + 2, act);
       }
       const Rows r_dhb = sl.rows_of(s_dhb), r_db = sl.rows_of(s_dboth);
       ffor<HFT>([&](auto tc) { constexpr int t = decltype(tc)::v;
@@ -381,7 +405,7 @@ fused_train_backward_kernel(BwdArgs A) {
         const Rows r = sl.rows_of(s_dboth, br * HB);
         ffor<HBT>([&](auto tc) { constexpr int t = decltype(tc)::v; dout[t] = load_tile(r, t); });
         EpicB<HBT, ET, GB>::template output_bwd<HBT>(dx, dout, A.D[base_b + 4 + 4 * nb], A.P, LB.dgcat + br * GB, LB, sl,
-                                                     tid);
+                                                     tid, act);
       }
       if (use_skip) {
         f32x16 z;
@@ -393,9 +417,9 @@ fused_train_backward_kernel(BwdArgs A) {
       for (int i = nb - 1; i >= 0; --i) {
         const uint64_t j = (uint64_t)(br * nb0 + i);
         EpicB<HBT, ET, GB>::layer_bwd(dx, A.D + base_b + 4 + 4 * i, A.P, use_skip, LB, S, sl, m, tid, A.drop_p, A.seed,
-                                      A.offset0 + 2 * j + 1, A.offset0 + 2 * j + 2);
+                                      A.offset0 + 2 * j + 1, A.offset0 + 2 * j + 2, act);
       }
-      EpicB<HBT, ET, GB>::template project_bwd<(br == 0 ? DM::EC : 0)>(dx, A.D + base_b, A.P, use_skip, LB, S, sl, m, tid);
+      EpicB<HBT, ET, GB>::template project_bwd<(br == 0 ? DM::EC : 0)>(dx, A.D + base_b, A.P, use_skip, LB, S, sl, m, tid, act);
       __syncthreads();
     });
     float* dt = sl.row_of(s_dtemb, ET);
@@ -412,16 +436,22 @@ fused_uni_train_backward_kernel(BwdArgs A) {
   static_assert(DM::V == 8, "fused path is instantiated for vocab_size 8");
   __shared__ LdsB LB;
   __shared__ float4 S[DM::HT * 4 * FE_THREADS];
+  __shared__ int red_s[8];
+  __shared__ short order_s[32 * FE_WAVES];
   constexpr int HT = DM::HT, ET = DM::ET, G = DM::G;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = steer_wave((A.tiles & 2) != 0, threadIdx.x >> 6, lane, red_s);
+  const int tid = 64 * wave + lane, half = lane >> 5;
   const int nb = A.nb_branch;
   const bool use_skip = A.use_skip != 0;
-  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+  for (int bi = blockIdx.x; bi < A.B; bi += gridDim.x) {
+    const int b = A.jet_order ? A.jet_order[bi] : bi;
     __syncthreads();
-    const int p = 32 * wave + (lane & 31);
-    const bool valid = p < A.N;
+    const int slot = 32 * wave + (lane & 31);
+    const bool valid = slot < A.N;
+    const int p = jet_order((A.tiles & 1) != 0, A.maskf + (int64_t)b * A.N, A.N, slot, wave, lane, red_s, order_s);
     const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
     const float m = valid ? A.maskf[gp] : 0.0f;
+    const bool act = plan_tiles((A.tiles & 1) != 0, false, m, valid, wave, lane, red_s).active;
     if (tid == 0) LB.cnt = (float)A.counts[b];
     if (tid < 128) LB.dtemb[tid] = 0.0f;
     __syncthreads();
@@ -432,11 +462,11 @@ fused_uni_train_backward_kernel(BwdArgs A) {
     {
       f32x16 dout[1];
       zero_tiles<1>(dout);
-      if (valid && (gp + 1) * sd.ld <= sd.n) {
+      if (act && valid && (gp + 1) * sd.ld <= sd.n) {
         const float4 v = *reinterpret_cast<const float4*>(sd.p + gp * sd.ld + 4 * half);
         dout[0][0] = v.x; dout[0][1] = v.y; dout[0][2] = v.z; dout[0][3] = v.w;
       }
-      EpicB<HT, ET, G>::template output_bwd<1>(dx, dout, A.D[4 + 4 * nb], A.P, nullptr, LB, sl, tid, DM::V);
+      EpicB<HT, ET, G>::template output_bwd<1>(dx, dout, A.D[4 + 4 * nb], A.P, nullptr, LB, sl, tid, act, DM::V);
     }
     if (use_skip) {
       f32x16 z;
@@ -447,12 +477,18 @@ fused_uni_train_backward_kernel(BwdArgs A) {
     __syncthreads();
     for (int i = nb - 1; i >= 0; --i)
       EpicB<HT, ET, G>::layer_bwd(dx, A.D + 4 + 4 * i, A.P, use_skip, LB, S, sl, m, tid, A.drop_p, A.seed,
-                                  A.offset0 + 2 * (uint64_t)i + 1, A.offset0 + 2 * (uint64_t)i + 2);
-    EpicB<HT, ET, G>::template project_bwd<0>(dx, A.D, A.P, use_skip, LB, S, sl, m, tid);
+                                  A.offset0 + 2 * (uint64_t)i + 1, A.offset0 + 2 * (uint64_t)i + 2, act);
+    EpicB<HT, ET, G>::template project_bwd<0>(dx, A.D, A.P, use_skip, LB, S, sl, m, tid, act);
     __syncthreads();
     float* dt = sl.row_of(s_dtemb, ET);
     if (tid < ET && dt != nullptr) dt[tid] = LB.dtemb[tid];
   }
+}
+
+// MMB_TRAIN_TILES=<bits> (developer switch; default 3; csrc/fused_epic.hip reads the same variable for the forward)
+static int train_tiles() {
+  const char* e = getenv("MMB_TRAIN_TILES");
+  return e ? atoi(e) : 3;
 }
 
 }  // namespace mmb
@@ -461,18 +497,20 @@ using namespace mmb;
 
 #if MMB_FE_WAVES == 4
 extern "C" int mmb_fused_uni_train_backward_w5(int, int, int, const float*, const int32_t*, int, int, const float*,
-                                               const int32_t*, const void*, int, float, uint64_t, uint64_t, void*);
+                                               const int32_t*, const void*, int, float, uint64_t, uint64_t, const int32_t*,
+                                               void*);
 extern "C" int mmb_fused_epic_train_backward_w5(int, int, int, const float*, const int32_t*, int, int, int, int, const float*,
-                                                const int32_t*, const void*, int, float, uint64_t, uint64_t, void*);
+                                                const int32_t*, const void*, int, float, uint64_t, uint64_t, const int32_t*,
+                                                void*);
 #endif
 
 extern "C" int mmb_fused_uni_train_backward(int variant, int B, int N, const float* packed_bwd, const int32_t* desc_bwd,
                                             int num_blocks, int use_skip, const float* maskf, const int32_t* counts,
                                             const void* slots, int n_slots, float drop_p, uint64_t seed,
-                                            uint64_t offset0, void* stream) {
+                                            uint64_t offset0, const int32_t* jet_order, void* stream) {
 #if MMB_FE_WAVES == 4
   if (N > 128) return mmb_fused_uni_train_backward_w5(variant, B, N, packed_bwd, desc_bwd, num_blocks, use_skip, maskf, counts,
-                                                      slots, n_slots, drop_p, seed, offset0, stream);
+                                                      slots, n_slots, drop_p, seed, offset0, jet_order, stream);
 #endif
   MMB_REQUIRE(B > 0 && N > 0 && N <= 32 * FE_WAVES, "mmb_fused_uni_train_backward: needs 0 < N <= %d (got B=%d N=%d)", 32 * FE_WAVES, B, N);
   MMB_REQUIRE(packed_bwd && desc_bwd && maskf && counts && slots, "mmb_fused_uni_train_backward: NULL argument");
@@ -482,7 +520,7 @@ extern "C" int mmb_fused_uni_train_backward(int variant, int B, int N, const flo
   MMB_REQUIRE(n_slots == expect, "mmb_fused_uni_train_backward: %d slots given, the architecture has %d", n_slots,
               expect);
   BwdArgs A{packed_bwd, reinterpret_cast<const BDesc*>(desc_bwd), num_blocks, 0, use_skip, B, N, maskf,
-            counts, reinterpret_cast<const SaveSlot*>(slots), n_slots, drop_p, seed, offset0};
+            counts, reinterpret_cast<const SaveSlot*>(slots), n_slots, drop_p, seed, offset0, 0, train_tiles(), jet_order};
   const int grid = B < 4096 ? B : 4096;
   switch (variant) {
     case 0: hipLaunchKernelGGL(fused_uni_train_backward_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A); break;
@@ -497,10 +535,11 @@ extern "C" int mmb_fused_epic_train_backward(int variant, int B, int N, const fl
                                              int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip,
                                              const float* maskf,
                                              const int32_t* counts, const void* slots, int n_slots, float drop_p,
-                                             uint64_t seed, uint64_t offset0, void* stream) {
+                                             uint64_t seed, uint64_t offset0, const int32_t* jet_order, void* stream) {
 #if MMB_FE_WAVES == 4
   if (N > 128) return mmb_fused_epic_train_backward_w5(variant, B, N, packed_bwd, desc_bwd, nb_branch, nb_branch1, nb_fused_exec,
-                                                       use_skip, maskf, counts, slots, n_slots, drop_p, seed, offset0, stream);
+                                                       use_skip, maskf, counts, slots, n_slots, drop_p, seed, offset0, jet_order,
+                                                       stream);
 #endif
   MMB_REQUIRE(B > 0 && N > 0 && N <= 32 * FE_WAVES, "mmb_fused_epic_train_backward: needs 0 < N <= %d (got B=%d N=%d)", 32 * FE_WAVES, B, N);
   MMB_REQUIRE(packed_bwd && desc_bwd && maskf && counts && slots, "mmb_fused_epic_train_backward: NULL argument");
@@ -511,7 +550,7 @@ extern "C" int mmb_fused_epic_train_backward(int variant, int B, int N, const fl
   MMB_REQUIRE(n_slots == expect, "mmb_fused_epic_train_backward: %d slots given, the architecture has %d", n_slots,
               expect);
   BwdArgs A{packed_bwd, reinterpret_cast<const BDesc*>(desc_bwd), nb_branch, nb_fused_exec, use_skip, B, N, maskf,
-            counts, reinterpret_cast<const SaveSlot*>(slots), n_slots, drop_p, seed, offset0, nb_branch1};
+            counts, reinterpret_cast<const SaveSlot*>(slots), n_slots, drop_p, seed, offset0, nb_branch1, train_tiles(), jet_order};
   const int grid = B < 4096 ? B : 4096;
   switch (variant) {
     case 0: hipLaunchKernelGGL(fused_train_backward_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A); break;

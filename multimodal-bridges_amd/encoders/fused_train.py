@@ -36,7 +36,9 @@ class _Plan:
         return t
 
     def rows(self, width):                       # one row per particle
-        return self.slot(torch.empty(self.M, width, dtype=torch.float32, device=self.dev))
+        # zeros, not empty: the kernels leave the rows of idle tiles (padded slots only) unwritten, and the weight-gradient
+        # GEMMs multiply them by gradient rows that are exactly zero -- whatever is there must be finite
+        return self.slot(torch.zeros(self.M, width, dtype=torch.float32, device=self.dev))
 
     def jets(self, width):                       # one row per jet
         return self.slot(torch.empty(self.B, width, dtype=torch.float32, device=self.dev))

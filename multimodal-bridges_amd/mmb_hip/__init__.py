@@ -69,9 +69,9 @@ SIGNATURES = {
                                c_stream],
     "mmb_fused_epic_train_forward": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, c_f32p, c_i32p, c_f32p, c_i64p, c_f32p, C.c_int64, C.c_void_p,
-                                     C.c_int, C.c_float, C.c_uint64, C.c_uint64, c_f32p, c_f32p, c_stream],
+                                     C.c_int, C.c_float, C.c_uint64, C.c_uint64, c_f32p, c_f32p, c_i32p, c_stream],
     "mmb_fused_epic_train_backward": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
-                                      c_i32p, C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint64, c_stream],
+                                      c_i32p, C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint64, c_i32p, c_stream],
     "mmb_grad_weight_smallk": [C.c_int, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p,
                                c_stream],
     "mmb_weight_norm_multi": [C.c_int, C.c_void_p, c_stream],
@@ -80,9 +80,9 @@ SIGNATURES = {
     "mmb_grad_weight_rows_multi": [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, c_stream],
     "mmb_fused_uni_train_forward": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, c_f32p, c_i32p,
                                     c_i64p, c_f32p, C.c_int64, C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint64,
-                                    c_f32p, c_stream],
+                                    c_f32p, c_i32p, c_stream],
     "mmb_fused_uni_train_backward": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, c_f32p, c_i32p,
-                                     C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint64, c_stream],
+                                     C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint64, c_i32p, c_stream],
     "mmb_fused_epic_generate": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, c_f32p, c_i32p, c_f32p, c_i64p, C.c_int, c_f32p, c_f32p, c_f32p,
                                 C.c_int, C.c_float,

@@ -660,7 +660,8 @@ def train_forward(pack, mi, x, k, temb, slots, n_slots, drop_p, seed, offset0, h
     call("mmb_fused_epic_train_forward", pack["variant"], B, N, f32(pack["packed"]), i32(pack["desc"]),
          pack["nb_branch"], pack["nb_branch1"], pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"],
          pack["off_table"], f32(mi.maskf), i32(mi.counts), f32(x, "x"), i64(k, "k"), f32(temb, "temb"), temb.stride(0),
-         C.c_void_p(slots.data_ptr()), n_slots, _fl(drop_p), seed, offset0, f32(hc), f32(hd), stream())
+         C.c_void_p(slots.data_ptr()), n_slots, _fl(drop_p), seed, offset0, f32(hc), f32(hd), i32(jet_schedule(mi)),
+         stream())
     return hc, hd
 
 
@@ -669,7 +670,7 @@ def train_forward_uni(pack, mi, k, temb, slots, n_slots, drop_p, seed, offset0, 
     call("mmb_fused_uni_train_forward", pack["variant"], mi.B, mi.N, f32(pack["packed"]), i32(pack["desc"]),
          pack["num_blocks"], pack["use_skip"], pack["off_table"], f32(mi.maskf), i32(mi.counts), i64(k, "k"),
          f32(temb, "temb"), temb.stride(0), C.c_void_p(slots.data_ptr()), n_slots, _fl(drop_p), seed, offset0, f32(hd),
-         stream())
+         i32(jet_schedule(mi)), stream())
     return hd
 
 
@@ -679,17 +680,17 @@ def train_backward(pack, pbwd, mi, slots, n_slots, drop_p, seed, offset0):
     if pack["kind"] == "uni":
         call("mmb_fused_uni_train_backward", pack["variant"], mi.B, mi.N, f32(pbwd), i32(pack["desc_bwd"]),
              pack["num_blocks"], pack["use_skip"], f32(mi.maskf), i32(mi.counts), C.c_void_p(slots.data_ptr()), n_slots,
-             _fl(drop_p), seed, offset0, stream())
+             _fl(drop_p), seed, offset0, i32(jet_schedule(mi)), stream())
         return
     call("mmb_fused_epic_train_backward", pack["variant"], mi.B, mi.N, f32(pbwd), i32(pack["desc_bwd"]), pack["nb_branch"],
          pack["nb_branch1"], pack["nb_fused_exec"], pack["use_skip"], f32(mi.maskf), i32(mi.counts),
          C.c_void_p(slots.data_ptr()), n_slots,
-         _fl(drop_p), seed, offset0, stream())
+         _fl(drop_p), seed, offset0, i32(jet_schedule(mi)), stream())
 
 
 def jet_schedule(mi):
-    """(B) int32 launch order of the jets of a generation call: longest first (csrc/fused_epic.hip: jet_schedule_kernel);
-    kept with the mask it was computed from."""
+    """(B) int32 launch order of the jets of a fused generation or training call: heaviest and lightest jets in
+    alternating rounds (csrc/fused_epic.hip: jet_schedule_kernel); kept with the mask it was computed from."""
     order = getattr(mi, "_order", None)
     if order is None:
         order = torch.empty(mi.B, dtype=torch.int32, device=mi.maskf.device)

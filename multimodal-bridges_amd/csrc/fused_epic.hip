@@ -845,6 +845,10 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
     for (int d = 0; d < DM::DC; ++d) xp[d] = valid ? x[gp * DM::DC + d] : 0.0f;
     int kp = valid ? (int)k[gp] : 0;
     const TilePlan tp = plan_tiles((Gn.tiles & 1) != 0, true, m, valid, wave, lane, L.red);
+    // The whole grid loop once per kind of tile (same barriers in both): a working tile runs the loop it ran before
+    // tiles could be idle, with that loop's register allocation; the idle one is a short loop of its own.
+    auto grid_loop = [&](auto actc) __attribute__((always_inline)) {
+    constexpr bool ACT = decltype(actc)::v != 0;
     for (int s = 0; s < Gn.steps; ++s) {
       __syncthreads();
       if (tid < DM::ET) L.temb[tid] = Gn.temb_steps[(int64_t)s * DM::ET + tid];
@@ -867,15 +871,19 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
       // Euler step on the drift head (solvers.py:21-25); padded slots move too (K3)
       park();
       NoTrain nt;
-      if (tp.active) forward_jet<DM, true, true>(A, L, S, xp, kp, m, 0, hc, hd, tid, ring, nt);
-      else forward_jet<DM, true, false>(A, L, S, xp, kp, m, 0, hc, hd, tid, ring, nt);
+      forward_jet<DM, true, ACT>(A, L, S, xp, kp, m, 0, hc, hd, tid, ring, nt);
       unpark();
       {
-        float v[3] = {hc[0], hc[1], hc[2]};
-        if (tp.idle_any) {
-          if (tp.rep) { padv[0] = v[0]; padv[1] = v[1]; padv[2] = v[2]; }
+        float v[3] = {0.0f, 0.0f, 0.0f};
+        if constexpr (ACT) {
+          v[0] = hc[0]; v[1] = hc[1]; v[2] = hc[2];
+          if (tp.idle_any) {                             // (workgroup-uniform; an idle tile exists only when it is set)
+            if (tp.rep) { padv[0] = v[0]; padv[1] = v[1]; padv[2] = v[2]; }
+            __syncthreads();
+          }
+        } else if (tp.idle_any) {                        // (an idle tile without a valid slot needs nothing)
           __syncthreads();
-          if (!tp.active) { v[0] = padv[0]; v[1] = padv[1]; v[2] = padv[2]; }
+          v[0] = padv[0]; v[1] = padv[1]; v[2] = padv[2];
         }
         float w[4] = {0.f, 0.f, 0.f, 0.f};
         float sig = 0.0f;
@@ -908,24 +916,28 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
       __syncthreads();
       // tau-leap on the logits head, which sees the UPDATED x at the same t (solvers.py:59-81)
       park();
-      if (tp.active) forward_jet<DM, true, true>(A, L, S, xp, kp, m, 1, hc, hd, tid, ring, nt);
-      else forward_jet<DM, true, false>(A, L, S, xp, kp, m, 1, hc, hd, tid, ring, nt);
+      forward_jet<DM, true, ACT>(A, L, S, xp, kp, m, 1, hc, hd, tid, ring, nt);
       unpark();
       float r[V];
-      gather_logits<DM>(hd, r, lane);
-      if (tp.idle_any) {
-        if (tp.rep) {
+      if constexpr (ACT) {
+        gather_logits<DM>(hd, r, lane);
+        if (tp.idle_any) {
+          if (tp.rep) {
 #pragma unroll
-          for (int v = 0; v < V; ++v) padv[4 + v] = r[v];
+            for (int v = 0; v < V; ++v) padv[4 + v] = r[v];
+          }
+          __syncthreads();
         }
-        __syncthreads();
-        if (!tp.active) {
+      } else {
+        if (tp.idle_any) __syncthreads();
 #pragma unroll
-          for (int v = 0; v < V; ++v) r[v] = padv[4 + v];
-        }
+        for (int v = 0; v < V; ++v) r[v] = padv[4 + v];
       }
       kp = jump_step(r, kp, tt, Gn, s == Gn.steps - 1, valid, A.B, A.N, b, p, s, gp);
     }
+    };
+    if (tp.active) grid_loop(IF<1>{});
+    else grid_loop(IF<0>{});
     if (valid && half == 0) {
 #pragma unroll
       for (int d = 0; d < DM::DC; ++d) x[gp * DM::DC + d] = xp[d];
@@ -1105,6 +1117,8 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
     const float m = valid ? A.maskf[gp] : 0.0f;
     int kp = valid ? (int)k[gp] : 0;
     const TilePlan tp = plan_tiles((Gn.tiles & 1) != 0, true, m, valid, wave, lane, L.red);
+    auto grid_loop = [&](auto actc) __attribute__((always_inline)) {      // (the whole loop per kind of tile: see fused_generate_kernel)
+    constexpr bool ACT = decltype(actc)::v != 0;
     for (int s = 0; s < Gn.steps; ++s) {
       __syncthreads();
       if (tid < DM::ET) L.temb[tid] = Gn.temb_steps[(int64_t)s * DM::ET + tid];
@@ -1112,23 +1126,27 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
       A.ctab = Gn.ctab_steps + (int64_t)s * Gn.n_ctab * 128;
       f32x16 hd;
       NoTrain nt;
-      if (tp.active) forward_uni<DM, true, true>(A, L, S, tab, kp, m, hd, tid, ring, nt);
-      else forward_uni<DM, true, false>(A, L, S, tab, kp, m, hd, tid, ring, nt);
+      forward_uni<DM, true, ACT>(A, L, S, tab, kp, m, hd, tid, ring, nt);
       float r[8];
-      gather8(hd, r, lane);
-      if (tp.idle_any) {
-        if (tp.rep) {
+      if constexpr (ACT) {
+        gather8(hd, r, lane);
+        if (tp.idle_any) {
+          if (tp.rep) {
 #pragma unroll
-          for (int v = 0; v < 8; ++v) padv[v] = r[v];
+            for (int v = 0; v < 8; ++v) padv[v] = r[v];
+          }
+          __syncthreads();
         }
-        __syncthreads();
-        if (!tp.active) {
+      } else {
+        if (tp.idle_any) __syncthreads();
 #pragma unroll
-          for (int v = 0; v < 8; ++v) r[v] = padv[v];
-        }
+        for (int v = 0; v < 8; ++v) r[v] = padv[v];
       }
       kp = jump_step(r, kp, Gn.times[s], Gn, s == Gn.steps - 1, valid, A.B, A.N, b, p, s, gp);
     }
+    };
+    if (tp.active) grid_loop(IF<1>{});
+    else grid_loop(IF<0>{});
     if (valid && half == 0) k[gp] = kp;
   }
 }
@@ -1399,7 +1417,9 @@ extern "C" int mmb_jet_schedule(int B, const int32_t* counts, int32_t* order, vo
     chunk = atoi(e);
   } else {
     int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&chunk, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&chunk, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      chunk = 0;
   }
   hipLaunchKernelGGL(jet_schedule_kernel, dim3(1), dim3(1024), 0, as_stream(stream), counts, B, chunk, order);
   return check_launch("mmb_jet_schedule");

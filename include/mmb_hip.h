@@ -355,7 +355,9 @@ int mmb_grad_weight_smallk(int M, const float* X, int64_t x_ld, int K, const flo
  *   dv out, dg out, db out | NULL, length, replicas, replica stride of dW, of db}; outputs are ACCUMULATED (+=), like
  *   autograd accumulates into .grad: zero them before the first backward of a step.
  * mmb_grad_weight_rows_multi: records {X, dZ, dW, db | NULL, x_ld, dz_ld, dw_ld, rep_stride, db_stride, M, K, Nout,
- *   rows per block, replicas, blocks along rows, blocks along K windows, first block id, end block id}, all of tile
+ *   rows per block, replicas, blocks along rows, blocks along K windows, first block id, end block id, row list |
+ *   NULL, its length (device int32) | NULL -- with a row list (mmb_mask_rows) the reduction runs over those rows of X
+ *   and dZ only}, all of tile
  *   class (OTb, KTb) = mmb_hip.ops.gw_class(K, Nout); semantics per record as mmb_grad_weight_rows (fast path only:
  *   K, Nout, leading dimensions multiples of 4, 16-byte aligned operands). */
 int mmb_weight_norm_multi(int n_rows, const void* rows, void* stream);
@@ -563,6 +565,12 @@ int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, cons
                             int thermo_kind, float gamma, const float* delta_n,
                             uint64_t seed, uint64_t offset,
                             int em, float em_sigma, const float* delta_w, const int32_t* jet_order, void* stream);
+
+/* rows[offs[b] + i] = b*N + (slot of the i-th real particle of jet b): the flat rows of the real particles of a batch,
+ * ascending; offs (B) = exclusive prefix sum of the per-jet particle counts.  The reduction range of the per-particle
+ * weight-gradient problems of mmb_grad_weight_rows_multi (GwProb.rows / n_rows): the reference's autograd sums over
+ * every slot, but the rows of padded slots carry gradients that are exactly zero (masked losses). */
+int mmb_mask_rows(int B, int N, const float* maskf, const int32_t* offs, int32_t* rows, void* stream);
 
 /* Launch order for the generation loops: order (B) = the jets sorted by particle count (counts, as passed to the
  * generation call), descending.  No counterpart in the reference (its loop runs whole batches through dense layers);

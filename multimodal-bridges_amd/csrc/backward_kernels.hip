@@ -274,7 +274,17 @@ template <int OT, int KT, bool X6>
 __device__ __forceinline__ void
 grad_weight_rows_body(int M, const float* __restrict__ X, int64_t x_ld, int K, const float* __restrict__ dZ,
                       int64_t dz_ld, int Nout, float* __restrict__ dW, int64_t dw_ld, float* __restrict__ db,
-                      int rows_per_block, int replicas, int64_t rep_stride, int64_t db_stride, int bx, int by, int bz) {
+                      int rows_per_block, int replicas, int64_t rep_stride, int64_t db_stride, int bx, int by, int bz,
+                      const int32_t* __restrict__ rows = nullptr, const int32_t* __restrict__ n_rows = nullptr,
+                      int nbx = 1) {
+  // rows / n_rows (both or neither): the reduction runs over rows[0 .. *n_rows) of X and dZ instead of 0 .. M -- the
+  // rows of real particles (mmb_mask_rows).  Rows of padded slots carry gradient rows that are exactly zero (the losses
+  // are masked): on AOJ multiplicities that is 62 % of a per-particle problem.  The grid stays sized for M rows, and
+  // the list's length is only known on the device: the 16-row chunks are dealt out round-robin over the nbx row blocks
+  // (block bx takes chunk groups bx, bx + nbx, ...), so that every block gets its share of however many rows there are.
+  const bool listed = rows != nullptr && n_rows != nullptr;
+  if (listed) M = min(M, *n_rows);
+  if ((listed ? bx * 4 * 16 : bx * rows_per_block) >= M) return;
   constexpr int R = 16;                                  // rows per chunk
   {                                                      // this block's replica of the accumulators
     const int rep = bx % replicas;
@@ -290,8 +300,8 @@ grad_weight_rows_body(int M, const float* __restrict__ X, int64_t x_ld, int K, c
   __shared__ __attribute__((aligned(16))) float lds[LDSN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, i32 = lane & 31;
   const int o0 = bz * OW, k0 = by * KW;
-  const int r_begin = bx * rows_per_block;
-  const int r_end = min(M, r_begin + rows_per_block);
+  const int r_begin = listed ? bx * 4 * R : bx * rows_per_block;
+  const int r_end = listed ? M : min(M, r_begin + rows_per_block);
   float* xs = lds + wave * TILE;
   float* zs = xs + R * XP;
 
@@ -311,12 +321,20 @@ grad_weight_rows_body(int M, const float* __restrict__ X, int64_t x_ld, int K, c
   // (rows past the end are clamped here and zeroed at the park), so their number in flight is static and the park of
   // the older buffer waits for that buffer only.
   float4 xa[XF4], za[ZF4], xb[XF4], zb[ZF4];
-  auto load_chunk = [&](int row0, float4 (&xn)[XF4], float4 (&zn)[ZF4]) __attribute__((always_inline)) {
+  // Row list: the 16 row numbers of a chunk are ONE load by lanes 0..15 (row_ids), requested a whole iteration before
+  // the chunk's data loads need them and handed to the lanes by a bpermute -- a per-lane rows[] load in front of every
+  // data load put two dependent latencies into a stream that is latency-bound already.
+  auto row_ids = [&](int row0) __attribute__((always_inline)) -> int {
+    return listed ? rows[min(row0 + (lane & 15), r_end - 1)] : 0;
+  };
+  auto load_chunk = [&](int row0, int ids, float4 (&xn)[XF4], float4 (&zn)[ZF4]) __attribute__((always_inline)) {
     sfor<XF4>([&](auto c) { constexpr int i = decltype(c)::v;          // (no branch: rows AND columns clamped into
-      const int64_t rr = min(row0 + xr[i], r_end - 1);                 //  valid memory, zeroed at the park)
+      int64_t rr = min(row0 + xr[i], r_end - 1);                       //  valid memory, zeroed at the park)
+      if (listed) rr = __shfl(ids, xr[i], 64);
       xn[i] = *reinterpret_cast<const float4*>(X + rr * x_ld + min(k0 + xc[i], K - 4)); });
     sfor<ZF4>([&](auto c) { constexpr int i = decltype(c)::v;
-      const int64_t rr = min(row0 + zr[i], r_end - 1);
+      int64_t rr = min(row0 + zr[i], r_end - 1);
+      if (listed) rr = __shfl(ids, zr[i], 64);
       zn[i] = *reinterpret_cast<const float4*>(dZ + rr * dz_ld + min(o0 + zc[i], Nout - 4)); });
   };
   auto park_chunk = [&](int row0, const float4 (&xn)[XF4], const float4 (&zn)[ZF4]) __attribute__((always_inline)) {
@@ -331,10 +349,14 @@ grad_weight_rows_body(int M, const float* __restrict__ X, int64_t x_ld, int K, c
   };
 
   // wave w owns chunks w, w+4, ... of the block
-  const int stride = 4 * R;
+  const int stride = listed ? 4 * R * nbx : 4 * R;
+  const bool two = listed || rows_per_block % (2 * stride) == 0;
   int row0 = r_begin + wave * R;
-  load_chunk(row0, xa, za);
-  if (rows_per_block % (2 * stride) == 0) load_chunk(row0 + stride, xb, zb);
+  int ida = row_ids(row0), idb = two ? row_ids(row0 + stride) : 0;
+  load_chunk(row0, ida, xa, za);
+  if (two) load_chunk(row0 + stride, idb, xb, zb);
+  ida = row_ids(row0 + (two ? 2 : 1) * stride);
+  if (two) idb = row_ids(row0 + 3 * stride);
   auto mma_chunk = [&]() __attribute__((always_inline)) {
     if constexpr (X6) {
       gw_bf16x8 ah[OT], am[OT], al[OT];
@@ -370,21 +392,24 @@ grad_weight_rows_body(int M, const float* __restrict__ X, int64_t x_ld, int K, c
     }
     }
   };
-  if (rows_per_block % (2 * stride) == 0) {
+  if (two) {
     // every wave owns an EVEN number of chunks (the last block's may lie past the end: clamped loads, zeroed dZ),
     // so both halves run unconditionally and the waits stay static
     for (; row0 < r_end; row0 += 2 * stride) {
       park_chunk(row0, xa, za);                         // (waits for buffer A only)
-      load_chunk(row0 + 2 * stride, xa, za);
+      load_chunk(row0 + 2 * stride, ida, xa, za);
+      ida = row_ids(row0 + 4 * stride);
       mma_chunk();
       park_chunk(row0 + stride, xb, zb);
-      load_chunk(row0 + 3 * stride, xb, zb);
+      load_chunk(row0 + 3 * stride, idb, xb, zb);
+      idb = row_ids(row0 + 5 * stride);
       mma_chunk();
     }
   } else {                                              // short blocks (per-jet problems): one buffer
     for (; row0 < r_end; row0 += stride) {
       park_chunk(row0, xa, za);
-      load_chunk(row0 + stride, xa, za);
+      load_chunk(row0 + stride, ida, xa, za);
+      ida = row_ids(row0 + 2 * stride);
       mma_chunk();
     }
   }
@@ -459,6 +484,8 @@ struct GwProb {            // all fields 8 bytes: built on the host as an int64 
   int64_t M, K, Nout, rpb, replicas;
   int64_t nbx, nby;        // blocks along the rows / the K windows (the rest of the range: output windows)
   int64_t block_begin, block_end;
+  const int32_t* rows;     // row list of the reduction (mmb_mask_rows) or NULL: all M rows
+  const int32_t* n_rows;   // its length, on the device
 };
 
 template <int OT, int KT, bool X6>
@@ -488,7 +515,24 @@ grad_weight_rows_multi_kernel(const GwProb* __restrict__ probs, int n_probs) {
     bz = rest / nby;
   }
   grad_weight_rows_body<OT, KT, X6>((int)q.M, q.X, q.x_ld, (int)q.K, q.dZ, q.dz_ld, (int)q.Nout, q.dW, q.dw_ld, q.db,
-                                (int)q.rpb, (int)q.replicas, q.rep_stride, q.db_stride, bx, by, bz);
+                                (int)q.rpb, (int)q.replicas, q.rep_stride, q.db_stride, bx, by, bz, q.rows, q.n_rows, nbx);
+}
+
+// rows[offs[b] + i] = b N + (slot of the i-th real particle of jet b): the flat rows of the real particles, ascending.
+// offs: exclusive prefix sum of the per-jet particle counts.  One wave per jet.
+__global__ void __launch_bounds__(256)
+mask_rows_kernel(int B, int N, const float* __restrict__ maskf, const int32_t* __restrict__ offs, int32_t* __restrict__ rows) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  int at = offs[b];
+  for (int p0 = 0; p0 < N; p0 += 64) {
+    const int p = p0 + lane;
+    const bool real = p < N && maskf[(int64_t)b * N + p] != 0.0f;
+    const unsigned long long bal = __ballot(real);
+    if (real) rows[at + __popcll(bal & ((1ull << lane) - 1ull))] = b * N + p;
+    at += __popcll(bal);
+  }
 }
 
 // dW[o][k] += sum_rows dZ[row][o] X[row][k], db[o] += sum_rows dZ[row][o] for a VERY narrow input (K <= 4: the
@@ -534,6 +578,13 @@ static bool gw_x6() {
 }  // namespace mmb
 
 using namespace mmb;
+
+extern "C" int mmb_mask_rows(int B, int N, const float* maskf, const int32_t* offs, int32_t* rows, void* stream) {
+  MMB_REQUIRE(B > 0 && N > 0 && maskf && offs && rows, "mmb_mask_rows: bad argument (B=%d N=%d)", B, N);
+  MMB_REQUIRE((int64_t)B * N < (1ll << 31), "mmb_mask_rows: B*N = %lld rows do not fit 32-bit row indices", (long long)B * N);
+  hipLaunchKernelGGL(mask_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(stream), B, N, maskf, offs, rows);
+  return check_launch("mmb_mask_rows");
+}
 
 extern "C" int mmb_grad_weight_smallk(int M, const float* X, int64_t x_ld, int K, const float* dZ, int64_t dz_ld,
                                       int Nout, float* dW, int64_t dw_ld, float* db, void* stream) {

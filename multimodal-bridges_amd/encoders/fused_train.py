@@ -11,6 +11,8 @@ backward(): ONE launch (mmb_fused_epic_train_backward) runs the reverse pass of 
             gradients exactly as the layered reverse pass does.
 
 Reference: encoders/multimodal_epic.py:158-194, encoders/epic.py:71-107,145-159,187-208 and their autograd."""
+import os
+
 import torch
 
 from mmb_hip import fused as fused_epic
@@ -365,12 +367,19 @@ class Workspace:
                     self.generic.append((t, Z, dWs, db, reps, dWr.stride(0), dbr.stride(0)))
                 koff += Ks
             self.layers.append((r["layer"], dWr, dbr, R))
+        # per-particle problems reduce over the rows of real particles only (their dZ rows are the only non-zero ones):
+        # the list is refilled from the mask of every step (backward), the table points at these two buffers
+        self.rows = torch.zeros(M, dtype=torch.int32, device=dev)
+        self.n_rows = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.use_rows = os.environ.get("MMB_GW_ROWS", "1") != "0"
         self.gw = []
         for cls, plist in sorted(probs.items()):
             rpb = ops.gw_rows_per_block([(q[0].shape[0], q[0].shape[1], q[1].shape[1]) for q in plist])
             recs, nblk = [], 0
             for q in plist:
-                rec, n = ops.gw_record(*q, nblk, rpb_big=rpb)
+                per_particle = self.use_rows and q[0].shape[0] == M and M > B
+                rec, n = ops.gw_record(*q, nblk, rpb_big=rpb, rows=self.rows if per_particle else None,
+                                       n_rows=self.n_rows if per_particle else None)
                 recs.append(rec)
                 nblk += n
             self.gw.append((cls, torch.tensor(recs, dtype=torch.int64).to(dev), len(recs), nblk))
@@ -460,6 +469,9 @@ class Workspace:
         bp = self.bp
         fused_epic.train_backward(pack, pbwd, st.mi, bp["table"], bp["n"], st.drop_p, st.seed, st.offset0)
         self.arena.zero_()
+        if self.use_rows:
+            ops.mask_rows(st.mi, self.rows)
+            self.n_rows.copy_(st.mi.total)
         for cls, table, n, nblk in self.gw:
             ops.grad_weight_rows_multi(cls, table, n, nblk)
         for X, Z, dWs, db, reps, rs, ds in self.generic:

@@ -520,8 +520,17 @@ def gw_rows_per_block(problems):
     return 512
 
 
-def gw_record(X, dZ, dW, db, replicas, rep_stride, db_stride, block_begin, rpb_big=512):
-    """One GwProb record (list of 18 ints) + the number of blocks it takes."""
+def mask_rows(mi, rows):
+    """rows (B*N) int32 <- the flat rows of the real particles, ascending (the first mi.total of them are valid): the
+    reduction range of the per-particle weight-gradient problems (csrc/backward_kernels.hip: mask_rows_kernel)."""
+    offs = torch.cumsum(mi.counts, 0, dtype=torch.int32) - mi.counts
+    call("mmb_mask_rows", mi.B, mi.N, f32(mi.maskf), i32(offs), i32(rows), stream())
+    return rows
+
+
+def gw_record(X, dZ, dW, db, replicas, rep_stride, db_stride, block_begin, rpb_big=512, rows=None, n_rows=None):
+    """One GwProb record (list of 20 ints) + the number of blocks it takes.  rows / n_rows: device row list and its
+    length (mask_rows) for a per-particle problem, or None."""
     M, K = X.shape
     Nout = dZ.shape[1]
     OTb, KTb = gw_class(K, Nout)
@@ -531,7 +540,8 @@ def gw_record(X, dZ, dW, db, replicas, rep_stride, db_stride, block_begin, rpb_b
     nbz = ((Nout + 31) // 32 + OTb - 1) // OTb
     n = nbx * nby * nbz
     rec = [X.data_ptr(), dZ.data_ptr(), dW.data_ptr(), 0 if db is None else db.data_ptr(), X.stride(0), dZ.stride(0),
-           dW.stride(0), rep_stride, db_stride, M, K, Nout, rpb, replicas, nbx, nby, block_begin, block_begin + n]
+           dW.stride(0), rep_stride, db_stride, M, K, Nout, rpb, replicas, nbx, nby, block_begin, block_begin + n,
+           0 if rows is None else rows.data_ptr(), 0 if n_rows is None else n_rows.data_ptr()]
     return rec, (n + 7) // 8 * 8          # ranges start on multiples of 8 (XCD-aware block order); gap blocks idle
 
 

@@ -147,9 +147,18 @@ def training_roofline(model, config, workload, B, training):
                        "peak_fp32": PEAK_FP32_MFMA_TFLOPS, "flops_per_particle_fwd": fpp, "passes": 3}
         pack = model._fused_pack() if hasattr(model, "_fused_pack") else None
         if pack and pack.get("mfma_flops_per_forward"):
-            ex = 6.0 * 3.0 * float(pack["mfma_flops_per_forward"]) * P / sec / 1e12
+            # executed: forward and reverse pass on the tiles that hold a real particle, weight gradients on the rows
+            # of real particles (training["batch_work"]; 1.0 each when the switches are off or the masks are full)
+            w = training.get("batch_work") or {}
+            tiles_on = int(os.environ.get("MMB_TRAIN_TILES", "3")) & 1
+            rows_on = os.environ.get("MMB_GW_ROWS", "1") != "0"
+            share = 2.0 * (w.get("working_tiles_frac", 1.0) if tiles_on else 1.0) + \
+                (w.get("real_rows_frac", 1.0) if rows_on else 1.0)
+            ex = 6.0 * share * float(pack["mfma_flops_per_forward"]) * P / sec / 1e12
             out["mfma"].update({"executed_bf16_tflops": ex, "frac_of_bf16_mfma_peak": ex / PEAK_BF16_MFMA_TFLOPS,
-                                "peak_bf16": PEAK_BF16_MFMA_TFLOPS})
+                                "peak_bf16": PEAK_BF16_MFMA_TFLOPS, "executed_passes": share,
+                                "note": "algorithmic_* count every slot of every jet, as the reference computes them; "
+                                        "executed_* what the kernels run after idle tiles and padded rows are skipped"})
     except Exception:                                          # not an EPiC encoder: count the Linear layers generically
         fpp = 0.0
         for m in model.encoder.modules():

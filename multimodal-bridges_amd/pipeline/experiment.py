@@ -405,7 +405,13 @@ def bench_training(model, config, B, device, dist, steps=10, warmup=3):
     model.train(was_training)
     for p in model.parameters():
         p.grad = None
-    return {"value": B * world * steps / dt, "unit": "jets/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+    # what the fused kernels skip on this batch: tiles without a real particle (forward, reverse), rows of padded slots
+    # (weight gradients) -- the bench's roofline counts executed work with these
+    n = tgt.mask.sum(dim=(1, 2))
+    N = tgt.mask.shape[1]
+    tiles = ((n + 31) // 32).clamp(max=(N + 31) // 32)
+    work = {"working_tiles_frac": float(tiles.sum()) / (B * ((N + 31) // 32)), "real_rows_frac": float(n.sum()) / (B * N)}
+    return {"value": B * world * steps / dt, "batch_work": work, "unit": "jets/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "global_batch": B * world, "dropout": config.encoder.dropout, "final_loss": float(loss.detach()),
             "optimizer": type(opt).__name__,
             "includes": "bridge sampling, fwd, loss, bwd, grad all-reduce, clip, AdamW",

@@ -777,3 +777,44 @@ def test_jet_schedule_is_a_permutation_heaviest_with_lightest(chunk, monkeypatch
                 assert torch.equal(c[(2 * q + 1) * chunk:(2 * q + 2) * chunk], srt.flip(0)[q * chunk:(q + 1) * chunk])
             assert torch.equal(c[2 * cp:], srt[cp:B - cp])
         assert fused.jet_schedule(mi) is mi._order               # computed once per mask
+
+
+def test_mask_rows_lists_the_real_particles_in_order():
+    """mmb_mask_rows: the flat rows of the real particles, ascending, whatever slots the masks mark (N not a multiple of
+    64, empty and full jets included)."""
+    from mmb_hip import ops
+    gen = torch.Generator().manual_seed(9)
+    for B, N in ((1, 16), (7, 128), (1024, 150), (33, 160)):
+        mask = (torch.rand(B, N, 1, generator=gen) < torch.rand(B, 1, 1, generator=gen)).long()
+        mask[0] = 1
+        if B > 2:
+            mask[1] = 0
+        mi = ops.mask_prepare(mask.cuda())
+        rows = torch.full((B * N,), -1, dtype=torch.int32, device="cuda")
+        ops.mask_rows(mi, rows)
+        want = torch.nonzero(mask.reshape(-1)).flatten().int()
+        assert int(mi.total) == want.numel()
+        assert torch.equal(rows[:want.numel()].cpu(), want)
+        assert bool((rows[want.numel():] == -1).all())
+
+
+@pytest.mark.parametrize("name", ["S3", "S2", "S3_n150"])
+def test_weight_gradients_over_real_rows_match_all_rows(golden, name, monkeypatch):
+    """The multi-problem weight-gradient launch reduces over the rows of real particles only (GwProb.rows); the rows it
+    leaves out carry gradient rows that are exactly zero, so every parameter gradient must match the all-rows launch to
+    summation order."""
+    res = {}
+    for rows_on in ("1", "0"):
+        monkeypatch.setenv("MMB_GW_ROWS", rows_on)
+        g = golden(name)
+        model = build(g).train()
+        model.use_fused_training, model.use_fused_backward = True, True
+        model.manual_seed(11)
+        from tensorclass import TensorMultiModal
+        c = lambda a: None if a is None else a.cuda()
+        t = g.t
+        state = TensorMultiModal(c(t["time"]), c(t.get("xt")), c(t["kt"]), c(t["mask"]))
+        out = model.step_from_state(state, batch_of(g), "train", True)
+        out["loss"].backward()
+        res[rows_on] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    grads_close(res["1"], res["0"], name, "fused_rows_vs_all_rows")

@@ -1,5 +1,5 @@
 import sys, os, time, yaml, torch
-ROOT='/root/repo'
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT+'/multimodal-bridges_amd'); sys.path.insert(0, ROOT)
 import bench
 for N, fused in ((128, True), (128, False), (150, True)):

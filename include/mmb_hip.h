@@ -555,7 +555,12 @@ int mmb_fused_uni_train_backward(int variant, int B, int N, const float* packed_
  * particles of a jet first (whatever slots the mask marks; noise.py:36-37 permutes every mask) and the padded slots of
  * idle tiles take drift and logits from one padded slot of a working tile: the same row, so they move exactly as before.
  * jet_order (B) | NULL: a permutation of the jets; workgroup i starts with jet jet_order[i].  A jet costs what its
- * working tiles cost, so longest-first (mmb_jet_schedule) keeps the last workgroups short; results do not depend on it. */
+ * working tiles cost, so longest-first (mmb_jet_schedule) keeps the last workgroups short; results do not depend on it.
+ * 128 < N <= 160 (AOJ's 150-slot clouds): the jets of fewer than 128 particles run on four waves, two to a CU, their
+ * slots beyond 128 -- padded ones -- carried as shadow slots; the others run in the five-wave kernel beside them, on a
+ * side stream of the library that is fenced by events on `stream`.  long_jets (n_long) | NULL: the jets of 128 or more
+ * particles and their number if the caller knows them (n_long = 0: none, one launch), n_long = -1 if it does not (every
+ * jet then gets a five-wave workgroup that leaves at once when its jet is short: ~15 ms slower).  Ignored for N <= 128. */
 int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, const int32_t* desc,
                             int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip,
                             int off_cw, int off_cb, int off_table,
@@ -564,7 +569,8 @@ int mmb_fused_epic_generate(int variant, int B, int N, const float* packed, cons
                             const float* ctab_steps, int n_ctab, float dt,
                             int thermo_kind, float gamma, const float* delta_n,
                             uint64_t seed, uint64_t offset,
-                            int em, float em_sigma, const float* delta_w, const int32_t* jet_order, void* stream);
+                            int em, float em_sigma, const float* delta_w, const int32_t* jet_order,
+                            const int32_t* long_jets, int n_long, void* stream);
 
 /* rows[offs[b] + i] = b*N + (slot of the i-th real particle of jet b): the flat rows of the real particles of a batch,
  * ascending; offs (B) = exclusive prefix sum of the per-jet particle counts.  The reduction range of the per-particle

@@ -910,26 +910,44 @@ __device__ __forceinline__ TilePlan plan_tiles(bool on, bool need_rep, float m, 
 // every mask (distributions/noise.py:36-37).  EPiC is permutation-equivariant: a particle's row does not depend on its
 // slot, only the pooled sums move in their last bits with the order of summation (not at all for a mask that already is
 // a prefix).  Injected noise and the Philox keys stay indexed by the true slot.  Returns the true slot behind `slot`.
+// CH: 32-slot chunks of a jet per wave.  1 in general; 2 when the four-wave generation kernel takes a jet of up to 160
+// slots whose real particles fit four tiles (chunk c of wave w = slots 32 (w + c FE_WAVES) ...): p[c] receives the true
+// slot behind this lane's ordered slot of chunk c.
+template <int CH, class OT>
+__device__ __forceinline__ void jet_order_n(bool on, const float* maskf, int N, int wave, int lane, int* red, OT* order,
+                                            int (&p)[CH]) {
+  static_assert(FE_WAVES * CH <= 8, "jet_order_n: red[] holds eight chunk counts");
+  int slot[CH];
+  ffor<CH>([&](auto cc) { constexpr int c = decltype(cc)::v; slot[c] = 32 * (wave + c * FE_WAVES) + (lane & 31); p[c] = slot[c]; });
+  if (!on) return;
+  float m[CH];
+  unsigned real_b[CH], pad_b[CH];
+  ffor<CH>([&](auto cc) { constexpr int c = decltype(cc)::v;
+    const bool valid = slot[c] < N;
+    m[c] = valid ? maskf[slot[c]] : 0.0f;
+    real_b[c] = (unsigned)__ballot(m[c] != 0.0f);                            // lanes 0..31 (32..63 repeat them)
+    pad_b[c] = (unsigned)__ballot(valid && m[c] == 0.0f); });
+  __syncthreads();                                       // the readers of red's last use
+  if (lane == 0)
+    ffor<CH>([&](auto cc) { constexpr int c = decltype(cc)::v;
+      red[wave + c * FE_WAVES] = __popc(real_b[c]) | (__popc(pad_b[c]) << 8); });
+  __syncthreads();
+  int n_real = 0;
+  for (int w = 0; w < FE_WAVES * CH; ++w) n_real += red[w] & 255;
+  const unsigned below = (1u << (lane & 31)) - 1u;
+  ffor<CH>([&](auto cc) { constexpr int c = decltype(cc)::v;
+    int real_before = 0, pad_before = 0;
+    for (int w = 0; w < wave + c * FE_WAVES; ++w) { const int f = red[w]; real_before += f & 255; pad_before += f >> 8; }
+    const int pos = m[c] != 0.0f ? real_before + __popc(real_b[c] & below) : n_real + pad_before + __popc(pad_b[c] & below);
+    if (slot[c] < N && lane < 32) order[pos] = (OT)slot[c]; });
+  __syncthreads();
+  ffor<CH>([&](auto cc) { constexpr int c = decltype(cc)::v; if (slot[c] < N) p[c] = order[slot[c]]; });
+}
 __device__ __forceinline__ int jet_order(bool on, const float* maskf, int N, int slot, int wave, int lane, int* red,
                                          short* order) {
-  if (!on) return slot;
-  const bool valid = slot < N;
-  const float m = valid ? maskf[slot] : 0.0f;
-  const unsigned real_b = (unsigned)__ballot(m != 0.0f), pad_b = (unsigned)__ballot(valid && m == 0.0f);   // lanes 0..31
-  __syncthreads();                                       // the readers of red's last use
-  if (lane == 0) red[wave] = __popc(real_b) | (__popc(pad_b) << 8);
-  __syncthreads();
-  int n_real = 0, real_before = 0, pad_before = 0;
-  for (int w = 0; w < FE_WAVES; ++w) {
-    const int f = red[w];
-    n_real += f & 255;
-    if (w < wave) { real_before += f & 255; pad_before += f >> 8; }
-  }
-  const unsigned below = (1u << (lane & 31)) - 1u;
-  const int pos = m != 0.0f ? real_before + __popc(real_b & below) : n_real + pad_before + __popc(pad_b & below);
-  if (valid && lane < 32) order[pos] = (short)slot;
-  __syncthreads();
-  return valid ? order[slot] : slot;
+  int p[1];
+  jet_order_n<1, short>(on, maskf, N, wave, lane, red, order, p);
+  return p[0];
 }
 
 // Two jets share a CU, one wave of each on every SIMD, and most jets leave tiles idle: which SIMDs the working tiles sit

@@ -437,7 +437,8 @@ struct GenArgs {
   const float* delta_w;      // (steps,B,N,DC) injected Wiener increments or NULL -> Philox/Box-Muller
   int stagger;               // core-clock cycles the second workgroup of a CU waits before its first forward (0: none)
   int tiles;                 // bit 0: tiles of padded slots only stay idle (TilePlan); bit 1: tiles steered to SIMDs
-  const int32_t* jet_order;  // (B) a permutation of the jets, workgroup i starts with jet_order[i]; NULL: 0, 1, 2, ...
+  const int32_t* jet_order;  // (n_jets) the jets of this launch, workgroup i starts with jet_order[i]; NULL: 0, 1, 2, ...
+  int n_jets;                // entries of jet_order (B: a permutation of all jets; fewer: the listed jets only)
 };
 
 // Two jets share a CU and run the SAME program: started together they stay in lock-step -- both in their GEMMs
@@ -812,14 +813,22 @@ __device__ __forceinline__ int jump_step(float (&r)[8], int kp, float tt, const 
   return hit >= 0 ? hit : kp;
 }
 
-template <class DM, int NWT = FE_WAVES>        // (NWT: a name of its own per wave count, the two compilations link together)
+// CH = 2 (four-wave build, 128 < N <= 160): the jets whose real particles fit four tiles -- fewer than 128 of them:
+// 99.97 % of AOJ's 150-slot clouds -- run here, two to a CU, instead of in the five-wave build at one per CU.  Their
+// slots beyond the four tiles are padded slots without a wave of their own: every lane of wave 0 carries one of them
+// as a shadow (ordered slot + 128), state in LDS, moved by the representative's drift and logits like the slots of an
+// idle tile.  The few longer jets are left to the five-wave launch of the same call (bit 2 of Gn.tiles: a split call).
+template <class DM, int NWT = FE_WAVES, int CH = 1>       // (NWT: a name of its own per wave count, the two compilations link together)
 __global__ void __launch_bounds__(FE_THREADS, FE_WAVES == 4 ? 2 : 1)
 fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* __restrict__ k) {
   __shared__ Lds L;
   __shared__ float4 S[DM::HFT * 4 * FE_THREADS];
   __shared__ float park_s[4][FE_THREADS];  // x (3) and k of this lane's particle while a forward runs
   __shared__ float padv[12];               // drift (0..2) and logits (4..11) of the representative padded slot
-  __shared__ short order_s[32 * FE_WAVES];
+  // (two workgroups of this kernel fill a CU's 160 KB of LDS to the last KB: the slot map in bytes, and the shadow
+  // slots -- at most 32, all carried by wave 0, both lane halves holding the same values -- in 512 B)
+  __shared__ unsigned char order_s[32 * FE_WAVES * CH];
+  __shared__ float park2_s[CH > 1 ? 4 : 1][CH > 1 ? 32 : 1];             // state of the shadow slots, by lane & 31
   stagger_start(Gn.stagger, threadIdx.x, L.red);
   const int lane = threadIdx.x & 63, wave = steer_wave((Gn.tiles & 2) != 0, threadIdx.x >> 6, lane, L.red);
   const int tid = 64 * wave + lane, half = lane >> 5;
@@ -831,13 +840,28 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
   __syncthreads();
   WRing<ring_depth_multi<DM>()> ring;
   ring_prime(ring, weight_rsrc(A.P), desc_wx(L, 0), lane * 16);
-  for (int bi = blockIdx.x; bi < A.B; bi += gridDim.x) {
+  for (int bi = blockIdx.x; bi < Gn.n_jets; bi += gridDim.x) {
     const int b = Gn.jet_order ? Gn.jet_order[bi] : bi;
+    // a split call: jets of 128 and more particles need a fifth tile (or the representative padded slot in it)
+    if ((Gn.tiles & 4) && (A.counts[b] >= 128) != (FE_WAVES == 5)) continue;
     __syncthreads();
     if (tid == 0) L.cnt = (float)A.counts[b];
     const int slot = 32 * wave + (lane & 31);
     const bool valid = slot < A.N;
-    const int p = jet_order((Gn.tiles & 1) != 0, A.maskf + (int64_t)b * A.N, A.N, slot, wave, lane, L.red, order_s);
+    int pp[CH];
+    jet_order_n<CH, unsigned char>((Gn.tiles & 1) != 0, A.maskf + (int64_t)b * A.N, A.N, wave, lane, L.red, order_s, pp);
+    const int p = pp[0];
+    const int p2 = pp[CH - 1];
+    const bool valid2 = CH > 1 && wave == 0 && slot + 32 * FE_WAVES < A.N;
+    const int l2 = lane & 31;
+    const int64_t gp2 = (int64_t)b * A.N + (valid2 ? p2 : 0);
+    if constexpr (CH > 1) {
+      if (valid2) {
+#pragma unroll
+        for (int d = 0; d < DM::DC; ++d) park2_s[d][l2] = x[gp2 * DM::DC + d];
+        park2_s[3][l2] = __int_as_float((int)k[gp2]);
+      }
+    }
     const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
     const float m = valid ? A.maskf[gp] : 0.0f;
     float xp[4] = {0.f, 0.f, 0.f, 0.f};
@@ -845,6 +869,7 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
     for (int d = 0; d < DM::DC; ++d) xp[d] = valid ? x[gp * DM::DC + d] : 0.0f;
     int kp = valid ? (int)k[gp] : 0;
     const TilePlan tp = plan_tiles((Gn.tiles & 1) != 0, true, m, valid, wave, lane, L.red);
+    const bool pub = tp.idle_any || CH > 1;                  // somebody needs the representative's heads
     // The whole grid loop once per kind of tile (same barriers in both): a working tile runs the loop it ran before
     // tiles could be idle, with that loop's register allocation; the idle one is a short loop of its own.
     auto grid_loop = [&](auto actc) __attribute__((always_inline)) {
@@ -877,27 +902,27 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
         float v[3] = {0.0f, 0.0f, 0.0f};
         if constexpr (ACT) {
           v[0] = hc[0]; v[1] = hc[1]; v[2] = hc[2];
-          if (tp.idle_any) {                             // (workgroup-uniform; an idle tile exists only when it is set)
+          if (pub) {                                     // (workgroup-uniform; an idle tile exists only when it is set)
             if (tp.rep) { padv[0] = v[0]; padv[1] = v[1]; padv[2] = v[2]; }
             __syncthreads();
           }
-        } else if (tp.idle_any) {                        // (an idle tile without a valid slot needs nothing)
+        } else if (pub) {                                // (an idle tile without a valid slot needs nothing)
           __syncthreads();
           v[0] = padv[0]; v[1] = padv[1]; v[2] = padv[2];
         }
-        float w[4] = {0.f, 0.f, 0.f, 0.f};
-        float sig = 0.0f;
-        if (Gn.em) {                                     // both lane halves draw the same increments
-          sig = Gn.em_sigma * sqrtf(tt * (1.0f - tt));
+        const float sig = Gn.em ? Gn.em_sigma * sqrtf(tt * (1.0f - tt)) : 0.0f;
+        auto wiener = [&](float (&w)[4], bool ok, int pt, int64_t gpt) {      // both lane halves draw the same increments
+          w[0] = w[1] = w[2] = w[3] = 0.0f;
+          if (!Gn.em) return;
           if (Gn.delta_w != nullptr) {
-            if (valid) {
-              const float* dw = Gn.delta_w + (((int64_t)s * A.B + b) * A.N + p) * DM::DC;
+            if (ok) {
+              const float* dw = Gn.delta_w + (((int64_t)s * A.B + b) * A.N + pt) * DM::DC;
 #pragma unroll
               for (int d = 0; d < DM::DC; ++d) w[d] = dw[d];
             }
           } else {
             uint32_t q[4];
-            philox4(Gn.seed, Gn.offset + (uint64_t)s, (uint64_t)gp, 0xE001u, q);
+            philox4(Gn.seed, Gn.offset + (uint64_t)s, (uint64_t)gpt, 0xE001u, q);
             // hardware v_sin/v_cos (argument in revolutions): distribution-level draws, and no
             // private-memory argument reduction inside the generation loop
             const float r0 = sqrtf(-2.0f * __logf(u01_open0(q[0]))), r1 = sqrtf(-2.0f * __logf(u01_open0(q[2])));
@@ -905,12 +930,23 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
             w[1] = r0 * __builtin_amdgcn_sinf(u01(q[1]));
             w[2] = r1 * __builtin_amdgcn_cosf(u01(q[3]));
           }
-        }
+        };
+        float w[4];
+        wiener(w, valid, p, gp);
 #pragma unroll
         for (int d = 0; d < DM::DC; ++d) {
           const float o = __shfl_xor(v[d], 32, 64);
           const float drift = half == 0 ? v[d] : o;
           xp[d] += Gn.em ? (Gn.dt * drift + sig * w[d]) : Gn.dt * drift;
+        }
+        if constexpr (CH > 1) {                          // the shadow slot: a padded slot, the representative's drift
+          if (valid2) {
+            float w2[4];
+            wiener(w2, true, p2, gp2);
+#pragma unroll
+            for (int d = 0; d < DM::DC; ++d)
+              park2_s[d][l2] += Gn.em ? (Gn.dt * padv[d] + sig * w2[d]) : Gn.dt * padv[d];
+          }
         }
       }
       __syncthreads();
@@ -921,7 +957,7 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
       float r[V];
       if constexpr (ACT) {
         gather_logits<DM>(hd, r, lane);
-        if (tp.idle_any) {
+        if (pub) {
           if (tp.rep) {
 #pragma unroll
             for (int v = 0; v < V; ++v) padv[4 + v] = r[v];
@@ -929,11 +965,20 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
           __syncthreads();
         }
       } else {
-        if (tp.idle_any) __syncthreads();
+        if (pub) __syncthreads();
 #pragma unroll
         for (int v = 0; v < V; ++v) r[v] = padv[4 + v];
       }
       kp = jump_step(r, kp, tt, Gn, s == Gn.steps - 1, valid, A.B, A.N, b, p, s, gp);
+      if constexpr (CH > 1) {
+        if (valid2) {
+          float r2[V];
+#pragma unroll
+          for (int v = 0; v < V; ++v) r2[v] = padv[4 + v];
+          const int k2 = jump_step(r2, __float_as_int(park2_s[3][l2]), tt, Gn, s == Gn.steps - 1, true, A.B, A.N, b, p2, s, gp2);
+          park2_s[3][l2] = __int_as_float(k2);
+        }
+      }
     }
     };
     if (tp.active) grid_loop(IF<1>{});
@@ -942,6 +987,13 @@ fused_generate_kernel(FusedArgs A, GenArgs Gn, float* __restrict__ x, int64_t* _
 #pragma unroll
       for (int d = 0; d < DM::DC; ++d) x[gp * DM::DC + d] = xp[d];
       k[gp] = kp;
+    }
+    if constexpr (CH > 1) {
+      if (valid2 && half == 0) {
+#pragma unroll
+        for (int d = 0; d < DM::DC; ++d) x[gp2 * DM::DC + d] = park2_s[d][l2];
+        k[gp2] = __float_as_int(park2_s[3][l2]);
+      }
     }
   }
 }
@@ -1106,7 +1158,7 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
   __syncthreads();
   WRing<ring_depth_uni<DM>()> ring;
   ring_prime(ring, weight_rsrc(A.P), desc_wx(L, 0), lane * 16);
-  for (int bi = blockIdx.x; bi < A.B; bi += gridDim.x) {
+  for (int bi = blockIdx.x; bi < Gn.n_jets; bi += gridDim.x) {
     const int b = Gn.jet_order ? Gn.jet_order[bi] : bi;
     __syncthreads();
     if (tid == 0) L.cnt = (float)A.counts[b];
@@ -1165,6 +1217,11 @@ static int gen_tiles() {
 }
 // MMB_TRAIN_TILES=<bits> (developer switch; default 3): the same two bits for the training kernels (forward and
 // reverse read it per call: both must run under the same setting, they share the tile order)
+// MMB_GEN_SPLIT=0 (developer switch): 128 < N <= 160 runs every jet in the five-wave build (no shadow slots)
+static int gen_split() {
+  const char* e = getenv("MMB_GEN_SPLIT");
+  return e ? atoi(e) : 1;
+}
 static int train_tiles() {
   const char* e = getenv("MMB_TRAIN_TILES");
   return e ? atoi(e) : 3;
@@ -1198,7 +1255,7 @@ extern "C" int mmb_fused_uni_generate_w5(int, int, int, const float*, const int3
 extern "C" int mmb_fused_epic_generate_w5(int, int, int, const float*, const int32_t*, int, int, int, int, int, int, int,
                                           const float*, const int32_t*, float*, int64_t*, int, const float*, const float*,
                                           const float*, int, float, int, float, const float*, uint64_t, uint64_t, int, float,
-                                          const float*, const int32_t*, void*);
+                                          const float*, const int32_t*, const int32_t*, int, void*);
 extern "C" int mmb_fused_epic_train_forward_w5(int, int, int, const float*, const int32_t*, int, int, int, int, int, int, int,
                                                const float*, const int32_t*, const float*, const int64_t*, const float*,
                                                int64_t, const void*, int, float, uint64_t, uint64_t, float*, float*,
@@ -1364,7 +1421,7 @@ extern "C" int mmb_fused_uni_generate(int variant, int B, int N, const float* pa
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), num_blocks, 0, use_skip, 0, 0, off_table, B, N,
               maskf, counts, 0, n_desc_uni(num_blocks)};
   GenArgs Gn{steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, (float)(-(double)8 * (double)gamma), delta_n,
-             seed, offset, 0, 0.0f, nullptr, stagger_cycles(0), gen_tiles(), jet_order};
+             seed, offset, 0, 0.0f, nullptr, stagger_cycles(0), gen_tiles(), jet_order, B};
   const int grid = B < 4096 ? B : 4096;
   switch (variant) {
     case 0: hipLaunchKernelGGL(fused_uni_generate_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k); break;
@@ -1630,13 +1687,32 @@ extern "C" int mmb_fused_epic_generate(int variant, int B, int N, const float* p
                                        const float* ctab_steps, int n_ctab, float dt,
                                        int thermo_kind, float gamma, const float* delta_n, uint64_t seed,
                                        uint64_t offset, int em, float em_sigma, const float* delta_w,
-                                       const int32_t* jet_order, void* stream) {
+                                       const int32_t* jet_order, const int32_t* long_jets, int n_long, void* stream) {
+  int tiles = gen_tiles();
+  // 128 < N <= 160 is a split call when tiles may be idle: the jets of fewer than 128 particles (AOJ: all but 3 in
+  // 10 000) run on four waves with shadow slots (CH = 2), two to a CU; the five-wave build (bit 8 of its `variant`
+  // says so) takes the rest.  Every workgroup of either launch leaves at once when its jet belongs to the other one.
+  bool shadows = false;
 #if MMB_FE_WAVES == 4
-  if (N > 128) return mmb_fused_epic_generate_w5(variant, B, N, packed, desc, nb_branch, nb_branch1, nb_fused_exec, use_skip, off_cw, off_cb,
-                                                 off_table, maskf, counts, x, k, steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind,
-                                                 gamma, delta_n, seed, offset, em, em_sigma, delta_w, jet_order, stream);
+  if (N > 128) {
+    shadows = (tiles & 1) != 0 && gen_split() != 0 && N <= 160;
+    if (!shadows)
+      return mmb_fused_epic_generate_w5(variant, B, N, packed, desc, nb_branch, nb_branch1, nb_fused_exec, use_skip, off_cw, off_cb,
+                                        off_table, maskf, counts, x, k, steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind,
+                                        gamma, delta_n, seed, offset, em, em_sigma, delta_w, jet_order, nullptr, -1, stream);
+    tiles |= 4;
+  }
+  const int n_jets = B;
+#else
+  int n_jets = B;
+  if (variant & 0x100) {                                 // the remainder launch of a split call
+    tiles |= 4;
+    variant &= 0xFF;
+    if (n_long >= 0) { jet_order = long_jets; n_jets = n_long; }       // the caller knows the long jets: only those
+  }
 #endif
-  int rc = check_fused("mmb_fused_epic_generate", B, N, packed, desc, maskf, counts, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec));
+  int rc = check_fused("mmb_fused_epic_generate", B, shadows ? 128 : N, packed, desc, maskf, counts,
+                       n_desc_multi(nb_branch, nb_branch1, nb_fused_exec));
   if (rc) return rc;
   MMB_REQUIRE(variant >= 0 && variant < N_MULTI_VARIANTS, "mmb_fused_epic_generate: unknown variant %d", variant);
   MMB_REQUIRE(x && k && times && temb_steps && steps > 0, "mmb_fused_epic_generate: NULL state / steps");
@@ -1645,13 +1721,54 @@ extern "C" int mmb_fused_epic_generate(int variant, int B, int N, const float* p
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
               off_table, B, N, maskf, counts, nb_branch1, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec)};
   GenArgs Gn{steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, (float)(-(double)8 * (double)gamma), delta_n, seed, offset,
-             em, em_sigma, delta_w, stagger_cycles(0), gen_tiles(), jet_order};
-  const int grid = B < 4096 ? B : 4096;
-  switch (variant) {
-    case 0: hipLaunchKernelGGL(fused_generate_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k); break;
-    case 1: hipLaunchKernelGGL(fused_generate_kernel<DimsMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k); break;
-    case 2: hipLaunchKernelGGL(fused_generate_kernel<DimsWide>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k); break;
-    default: hipLaunchKernelGGL(fused_generate_kernel<DimsNarrow>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k); break;
+             em, em_sigma, delta_w, stagger_cycles(0), tiles, jet_order, n_jets};
+  const int grid = n_jets < 4096 ? n_jets : 4096;
+#define MMB_GEN_LAUNCH(CHv)                                                                                                          \
+  switch (variant) {                                                                                                                 \
+    case 0: hipLaunchKernelGGL((fused_generate_kernel<DimsS3, FE_WAVES, CHv>), dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k); break;    \
+    case 1: hipLaunchKernelGGL((fused_generate_kernel<DimsMid, FE_WAVES, CHv>), dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k); break;   \
+    case 2: hipLaunchKernelGGL((fused_generate_kernel<DimsWide, FE_WAVES, CHv>), dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k); break;  \
+    default: hipLaunchKernelGGL((fused_generate_kernel<DimsNarrow, FE_WAVES, CHv>), dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, x, k); break; \
   }
+#if MMB_FE_WAVES == 4
+  if (shadows && n_long == 0) {                            // the caller knows there is no long jet: one launch
+    MMB_GEN_LAUNCH(2)
+    return check_launch("mmb_fused_epic_generate");
+  }
+  if (shadows) {
+    MMB_REQUIRE(n_long < 0 || (long_jets != nullptr && n_long <= B), "mmb_fused_epic_generate: long_jets / n_long = %d", n_long);
+    // The five-wave launch holds a handful of jets, each of which still takes a whole generation loop: behind the
+    // four-wave launch on one stream that is a third on top of the call.  It goes first, on a side stream per device
+    // that starts behind whatever precedes this call on the caller's stream (event e0) and is joined back (event e1)
+    // after the four-wave launch: the two write disjoint jets.  With the list of long jets (long_jets, n_long) it is
+    // n_long workgroups; without (n_long < 0) every jet gets a workgroup that leaves at once when its jet is short --
+    // but each of those needs an EMPTY CU to start (98 KB of LDS), which costs the four-wave launch ~15 ms.
+    struct Side { hipStream_t s = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; };
+    static Side sides[64];
+    int dev = 0;
+    MMB_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "mmb_fused_epic_generate: device index");
+    Side& sd = sides[dev];
+    if (sd.s == nullptr)
+      MMB_REQUIRE(hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&sd.e0, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&sd.e1, hipEventDisableTiming) == hipSuccess,
+                  "mmb_fused_epic_generate: side stream");
+    MMB_REQUIRE(hipEventRecord(sd.e0, as_stream(stream)) == hipSuccess && hipStreamWaitEvent(sd.s, sd.e0, 0) == hipSuccess,
+                "mmb_fused_epic_generate: fork of the side stream");
+    rc = mmb_fused_epic_generate_w5(variant | 0x100, B, N, packed, desc, nb_branch, nb_branch1, nb_fused_exec, use_skip, off_cw,
+                                    off_cb, off_table, maskf, counts, x, k, steps, times, temb_steps, ctab_steps, n_ctab, dt,
+                                    thermo_kind, gamma, delta_n, seed, offset, em, em_sigma, delta_w, jet_order, long_jets, n_long,
+                                    sd.s);
+    if (rc == MMB_OK) {
+      MMB_GEN_LAUNCH(2)
+      rc = check_launch("mmb_fused_epic_generate");
+    }
+    MMB_REQUIRE(hipEventRecord(sd.e1, sd.s) == hipSuccess && hipStreamWaitEvent(as_stream(stream), sd.e1, 0) == hipSuccess,
+                "mmb_fused_epic_generate: join of the side stream");
+    return rc;
+  }
+#endif
+  MMB_GEN_LAUNCH(1)
+#undef MMB_GEN_LAUNCH
   return check_launch("mmb_fused_epic_generate");
 }

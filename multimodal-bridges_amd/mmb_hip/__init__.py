@@ -87,7 +87,7 @@ SIGNATURES = {
                                 C.c_int, C.c_int, c_f32p, c_i32p, c_f32p, c_i64p, C.c_int, c_f32p, c_f32p, c_f32p,
                                 C.c_int, C.c_float,
                                 C.c_int, C.c_float, c_f32p, C.c_uint64, C.c_uint64, C.c_int, C.c_float, c_f32p,
-                                c_i32p, c_stream],
+                                c_i32p, c_i32p, C.c_int, c_stream],
     "mmb_jet_schedule": [C.c_int, c_i32p, c_i32p, c_stream],
     "mmb_mask_rows": [C.c_int, C.c_int, c_f32p, c_i32p, c_i32p, c_stream],
     "mmb_jet_observables": [C.c_int, C.c_int, C.c_int, c_f32p, c_i64p, c_f32p, c_f32p, c_stream],

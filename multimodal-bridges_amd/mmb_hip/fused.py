@@ -712,6 +712,19 @@ def working_tiles(counts, N):
     return t.clamp(max=all_tiles)
 
 
+def long_jets(mi):
+    """(list, count) of the jets with 128 or more particles, for a generation call at 128 < N <= 160: those need the
+    five-wave kernel, all others run on four waves with shadow slots (csrc/fused_epic.hip).  The count is read back --
+    one small synchronisation per mask, against a generation loop of tens of milliseconds -- because the remainder launch
+    is sized by it (and skipped when it is zero).  (None, -1) when N <= 128: not a split call."""
+    if mi.N <= 128 or os.environ.get("MMB_GEN_LONG_UNKNOWN"):      # (developer switch: the C ABI's "caller does not know" path)
+        return None, -1
+    if mi._long is None:
+        lst = torch.nonzero(mi.counts >= 128).flatten().to(torch.int32)
+        mi._long = (lst if lst.numel() else None, int(lst.numel()))
+    return mi._long
+
+
 def generate(pack, mi, x, k, times, temb_steps, dt, thermo_kind, gamma, delta_n=None, seed=0, offset=0, ctab=None,
              em_sigma=None, delta_w=None):
     """In-place generation loop on x (B,N,3) and k (B,N,1).  em_sigma is None -> Euler, else
@@ -720,12 +733,13 @@ def generate(pack, mi, x, k, times, temb_steps, dt, thermo_kind, gamma, delta_n=
     if ctab is None:                       # the kernels take the per-step time vectors from this table only
         ctab = time_vector_table(pack, temb_steps)
     n_ctab = ctab.shape[1]
+    lj, n_lj = long_jets(mi)
     call("mmb_fused_epic_generate", pack["variant"], B, N, f32(pack["packed"]), i32(pack["desc"]), pack["nb_branch"],
          pack["nb_branch1"], pack["nb_fused_exec"], pack["use_skip"], pack["off_cw"], pack["off_cb"], pack["off_table"],
          f32(mi.maskf), i32(mi.counts), f32(x, "x"), i64(k, "k"), times.numel(), f32(times, "times"), f32(temb_steps, "temb_steps"),
          f32(ctab, "ctab"), n_ctab, _fl(dt), thermo_kind, _fl(gamma), f32(delta_n, "delta_n"), seed, offset,
          0 if em_sigma is None else 1, _fl(0.0 if em_sigma is None else em_sigma), f32(delta_w, "delta_w"),
-         i32(jet_schedule(mi)), stream())
+         i32(jet_schedule(mi)), i32(lj), n_lj, stream())
 
 
 def forward_uni(pack, mi, k, temb, temb_stride=None):

@@ -52,13 +52,14 @@ def _fl(v):
 # ------------------------------------------------------------------------ masks / source
 class MaskInfo:
     """Canonical per-batch mask data: maskf (B,N) f32, counts (B) i32, total (1) i32."""
-    __slots__ = ("maskf", "counts", "total", "B", "N", "_compact", "_order")
+    __slots__ = ("maskf", "counts", "total", "B", "N", "_compact", "_order", "_long")
 
     def __init__(self, maskf, counts, total):
         self.maskf, self.counts, self.total = maskf, counts, total
         self.B, self.N = maskf.shape
         self._compact = None                       # row compaction of the transformer's inference path, built on demand
         self._order = None                         # launch order of the jets of a fused generation call, built on demand
+        self._long = None                          # jets of 128+ particles (fused generation at 128 < N <= 160), on demand
 
 
 def mask_prepare(mask):

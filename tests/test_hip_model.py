@@ -742,6 +742,18 @@ def test_idle_tiles_leave_generation_bit_identical(golden, name, monkeypatch):
         return (None if uni else paths.continuous[1].clone()), paths.discrete[1].clone()
 
     x_all, k_all = run(0)
+    if N > 128:
+        # 128 < N <= 160: jets of fewer than 128 particles run on four waves with shadow slots, the others in the
+        # five-wave kernel on a side stream -- with the list of long jets from the caller, and without it
+        monkeypatch.setenv("MMB_GEN_LONG_UNKNOWN", "1")
+        xs, ks = run(3)
+        monkeypatch.delenv("MMB_GEN_LONG_UNKNOWN")
+        x3, k3 = run(3)
+        assert torch.equal(ks, k3) and (uni or torch.equal(xs, x3))
+        monkeypatch.setenv("MMB_GEN_SPLIT", "0")             # every jet in the five-wave kernel
+        x5, k5 = run(3)
+        monkeypatch.delenv("MMB_GEN_SPLIT")
+        assert torch.equal(k5, k3) and (uni or torch.equal(x5, x3))
     prefix = torch.arange(B) < len(ns)                      # a prefix mask keeps its slot order: nothing may move at all
     m = mask.cuda() > 0
     for bits in (1, 3):

@@ -603,7 +603,8 @@ int mmb_fused_uni_generate(int variant, int B, int N, const float* packed, const
                            int steps, const float* times, const float* temb_steps,
                            const float* ctab_steps, int n_ctab, float dt,
                            int thermo_kind, float gamma, const float* delta_n,
-                           uint64_t seed, uint64_t offset, const int32_t* jet_order, void* stream);
+                           uint64_t seed, uint64_t offset, const int32_t* jet_order,
+                           const int32_t* long_jets, int n_long, void* stream);
 
 /* ---------------------------------------------------------------- toy config (BASELINE configs[0]) */
 /* Input rows of the toy MLP: rows[p,:] = [t(jet of p), x[p,0:Dc], table[k[p],0:E]]  (P, 1+Dc+E) --

@@ -1139,14 +1139,16 @@ fused_uni_train_forward_kernel(FusedArgs A, const int64_t* __restrict__ k, const
   }
 }
 
-template <class DM, int NWT = FE_WAVES>        // (NWT: a name of its own per wave count, the two compilations link together)
+// (CH = 2: 128 < N <= 160 on four waves with shadow slots, as fused_generate_kernel)
+template <class DM, int NWT = FE_WAVES, int CH = 1>       // (NWT: a name of its own per wave count, the two compilations link together)
 __global__ void __launch_bounds__(FE_THREADS, FE_WAVES == 4 ? 2 : 1)
 fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
   __shared__ Lds L;
   __shared__ float4 S[DM::HT * 4 * FE_THREADS];
   __shared__ __attribute__((aligned(16))) float tab[DM::V * DM::EDP];
   __shared__ float padv[8];                // logits of the representative padded slot (TilePlan)
-  __shared__ short order_s[32 * FE_WAVES];
+  __shared__ unsigned char order_s[32 * FE_WAVES * CH];
+  __shared__ int park2_k[CH > 1 ? 32 : 1]; // k of the shadow slots, by lane & 31
   stagger_start(Gn.stagger, threadIdx.x, L.red);
   const int lane = threadIdx.x & 63, wave = steer_wave((Gn.tiles & 2) != 0, threadIdx.x >> 6, lane, L.red);
   const int tid = 64 * wave + lane, half = lane >> 5;
@@ -1160,15 +1162,25 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
   ring_prime(ring, weight_rsrc(A.P), desc_wx(L, 0), lane * 16);
   for (int bi = blockIdx.x; bi < Gn.n_jets; bi += gridDim.x) {
     const int b = Gn.jet_order ? Gn.jet_order[bi] : bi;
+    if ((Gn.tiles & 4) && (A.counts[b] >= 128) != (FE_WAVES == 5)) continue;      // a split call: see fused_generate_kernel
     __syncthreads();
     if (tid == 0) L.cnt = (float)A.counts[b];
     const int slot = 32 * wave + (lane & 31);
     const bool valid = slot < A.N;
-    const int p = jet_order((Gn.tiles & 1) != 0, A.maskf + (int64_t)b * A.N, A.N, slot, wave, lane, L.red, order_s);
+    int pp[CH];
+    jet_order_n<CH, unsigned char>((Gn.tiles & 1) != 0, A.maskf + (int64_t)b * A.N, A.N, wave, lane, L.red, order_s, pp);
+    const int p = pp[0];
+    const int p2 = pp[CH - 1], l2 = lane & 31;
+    const bool valid2 = CH > 1 && wave == 0 && slot + 32 * FE_WAVES < A.N;
+    const int64_t gp2 = (int64_t)b * A.N + (valid2 ? p2 : 0);
+    if constexpr (CH > 1) {
+      if (valid2) park2_k[l2] = (int)k[gp2];
+    }
     const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
     const float m = valid ? A.maskf[gp] : 0.0f;
     int kp = valid ? (int)k[gp] : 0;
     const TilePlan tp = plan_tiles((Gn.tiles & 1) != 0, true, m, valid, wave, lane, L.red);
+    const bool pub = tp.idle_any || CH > 1;
     auto grid_loop = [&](auto actc) __attribute__((always_inline)) {      // (the whole loop per kind of tile: see fused_generate_kernel)
     constexpr bool ACT = decltype(actc)::v != 0;
     for (int s = 0; s < Gn.steps; ++s) {
@@ -1182,7 +1194,7 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
       float r[8];
       if constexpr (ACT) {
         gather8(hd, r, lane);
-        if (tp.idle_any) {
+        if (pub) {
           if (tp.rep) {
 #pragma unroll
             for (int v = 0; v < 8; ++v) padv[v] = r[v];
@@ -1190,16 +1202,27 @@ fused_uni_generate_kernel(FusedArgs A, GenArgs Gn, int64_t* __restrict__ k) {
           __syncthreads();
         }
       } else {
-        if (tp.idle_any) __syncthreads();
+        if (pub) __syncthreads();
 #pragma unroll
         for (int v = 0; v < 8; ++v) r[v] = padv[v];
       }
       kp = jump_step(r, kp, Gn.times[s], Gn, s == Gn.steps - 1, valid, A.B, A.N, b, p, s, gp);
+      if constexpr (CH > 1) {
+        if (valid2) {
+          float r2[8];
+#pragma unroll
+          for (int v = 0; v < 8; ++v) r2[v] = padv[v];
+          park2_k[l2] = jump_step(r2, park2_k[l2], Gn.times[s], Gn, s == Gn.steps - 1, true, A.B, A.N, b, p2, s, gp2);
+        }
+      }
     }
     };
     if (tp.active) grid_loop(IF<1>{});
     else grid_loop(IF<0>{});
     if (valid && half == 0) k[gp] = kp;
+    if constexpr (CH > 1) {
+      if (valid2 && half == 0) k[gp2] = park2_k[l2];
+    }
   }
 }
 
@@ -1222,6 +1245,24 @@ static int gen_split() {
   const char* e = getenv("MMB_GEN_SPLIT");
   return e ? atoi(e) : 1;
 }
+#if MMB_FE_WAVES == 4
+// the library's side stream of the current device (created at first use) and the two events that fence it
+struct SideStream { hipStream_t s = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; };
+static SideStream* side_stream() {
+  static SideStream sides[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  SideStream& sd = sides[dev];
+  if (sd.s == nullptr &&
+      !(hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&sd.e0, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&sd.e1, hipEventDisableTiming) == hipSuccess)) {
+    sd.s = nullptr;
+    return nullptr;
+  }
+  return &sd;
+}
+#endif
 static int train_tiles() {
   const char* e = getenv("MMB_TRAIN_TILES");
   return e ? atoi(e) : 3;
@@ -1251,7 +1292,7 @@ extern "C" int mmb_fused_uni_forward_w5(int, int, int, const float*, const int32
                                         const int32_t*, const int64_t*, const float*, int64_t, float*, void*);
 extern "C" int mmb_fused_uni_generate_w5(int, int, int, const float*, const int32_t*, int, int, int, const float*,
                                          const int32_t*, int64_t*, int, const float*, const float*, const float*, int, float,
-                                         int, float, const float*, uint64_t, uint64_t, const int32_t*, void*);
+                                         int, float, const float*, uint64_t, uint64_t, const int32_t*, const int32_t*, int, void*);
 extern "C" int mmb_fused_epic_generate_w5(int, int, int, const float*, const int32_t*, int, int, int, int, int, int, int,
                                           const float*, const int32_t*, float*, int64_t*, int, const float*, const float*,
                                           const float*, int, float, int, float, const float*, uint64_t, uint64_t, int, float,
@@ -1406,13 +1447,29 @@ extern "C" int mmb_fused_uni_generate(int variant, int B, int N, const float* pa
                                       const int32_t* counts, int64_t* k, int steps, const float* times,
                                       const float* temb_steps, const float* ctab_steps, int n_ctab, float dt,
                                       int thermo_kind, float gamma, const float* delta_n, uint64_t seed,
-                                      uint64_t offset, const int32_t* jet_order, void* stream) {
+                                      uint64_t offset, const int32_t* jet_order, const int32_t* long_jets, int n_long,
+                                      void* stream) {
+  int tiles = gen_tiles();
+  bool shadows = false;                                  // 128 < N <= 160: a split call, as mmb_fused_epic_generate
 #if MMB_FE_WAVES == 4
-  if (N > 128) return mmb_fused_uni_generate_w5(variant, B, N, packed, desc, num_blocks, use_skip, off_table, maskf, counts, k, steps,
-                                                times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, gamma, delta_n, seed, offset,
-                                                jet_order, stream);
+  if (N > 128) {
+    shadows = (tiles & 1) != 0 && gen_split() != 0 && N <= 160;
+    if (!shadows)
+      return mmb_fused_uni_generate_w5(variant, B, N, packed, desc, num_blocks, use_skip, off_table, maskf, counts, k, steps,
+                                       times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, gamma, delta_n, seed, offset,
+                                       jet_order, nullptr, -1, stream);
+    tiles |= 4;
+  }
+  const int n_jets = B;
+#else
+  int n_jets = B;
+  if (variant & 0x100) {                                 // the remainder launch of a split call
+    tiles |= 4;
+    variant &= 0xFF;
+    if (n_long >= 0) { jet_order = long_jets; n_jets = n_long; }
+  }
 #endif
-  int rc = check_fused("mmb_fused_uni_generate", B, N, packed, desc, maskf, counts, n_desc_uni(num_blocks));
+  int rc = check_fused("mmb_fused_uni_generate", B, shadows ? 128 : N, packed, desc, maskf, counts, n_desc_uni(num_blocks));
   if (rc) return rc;
   MMB_REQUIRE(variant >= 0 && variant < N_UNI_VARIANTS, "mmb_fused_uni_generate: unknown variant %d", variant);
   MMB_REQUIRE(k && times && temb_steps && steps > 0, "mmb_fused_uni_generate: NULL state / steps");
@@ -1421,14 +1478,40 @@ extern "C" int mmb_fused_uni_generate(int variant, int B, int N, const float* pa
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), num_blocks, 0, use_skip, 0, 0, off_table, B, N,
               maskf, counts, 0, n_desc_uni(num_blocks)};
   GenArgs Gn{steps, times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, (float)(-(double)8 * (double)gamma), delta_n,
-             seed, offset, 0, 0.0f, nullptr, stagger_cycles(0), gen_tiles(), jet_order, B};
-  const int grid = B < 4096 ? B : 4096;
-  switch (variant) {
-    case 0: hipLaunchKernelGGL(fused_uni_generate_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k); break;
-    case 1: hipLaunchKernelGGL(fused_uni_generate_kernel<UniMid>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k); break;
-    case 2: hipLaunchKernelGGL(fused_uni_generate_kernel<UniH64>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k); break;
-    default: hipLaunchKernelGGL(fused_uni_generate_kernel<UniH32>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k); break;
+             seed, offset, 0, 0.0f, nullptr, stagger_cycles(0), tiles, jet_order, n_jets};
+  const int grid = n_jets < 4096 ? n_jets : 4096;
+#define MMB_UNI_LAUNCH(CHv)                                                                                                          \
+  switch (variant) {                                                                                                                 \
+    case 0: hipLaunchKernelGGL((fused_uni_generate_kernel<UniS2, FE_WAVES, CHv>), dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k); break;   \
+    case 1: hipLaunchKernelGGL((fused_uni_generate_kernel<UniMid, FE_WAVES, CHv>), dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k); break;  \
+    case 2: hipLaunchKernelGGL((fused_uni_generate_kernel<UniH64, FE_WAVES, CHv>), dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k); break;  \
+    default: hipLaunchKernelGGL((fused_uni_generate_kernel<UniH32, FE_WAVES, CHv>), dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, Gn, k); break; \
   }
+#if MMB_FE_WAVES == 4
+  if (shadows && n_long == 0) {
+    MMB_UNI_LAUNCH(2)
+    return check_launch("mmb_fused_uni_generate");
+  }
+  if (shadows) {
+    MMB_REQUIRE(n_long < 0 || (long_jets != nullptr && n_long <= B), "mmb_fused_uni_generate: long_jets / n_long = %d", n_long);
+    SideStream* sd = side_stream();
+    MMB_REQUIRE(sd != nullptr, "mmb_fused_uni_generate: side stream");
+    MMB_REQUIRE(hipEventRecord(sd->e0, as_stream(stream)) == hipSuccess && hipStreamWaitEvent(sd->s, sd->e0, 0) == hipSuccess,
+                "mmb_fused_uni_generate: fork of the side stream");
+    rc = mmb_fused_uni_generate_w5(variant | 0x100, B, N, packed, desc, num_blocks, use_skip, off_table, maskf, counts, k, steps,
+                                   times, temb_steps, ctab_steps, n_ctab, dt, thermo_kind, gamma, delta_n, seed, offset, jet_order,
+                                   long_jets, n_long, sd->s);
+    if (rc == MMB_OK) {
+      MMB_UNI_LAUNCH(2)
+      rc = check_launch("mmb_fused_uni_generate");
+    }
+    MMB_REQUIRE(hipEventRecord(sd->e1, sd->s) == hipSuccess && hipStreamWaitEvent(as_stream(stream), sd->e1, 0) == hipSuccess,
+                "mmb_fused_uni_generate: join of the side stream");
+    return rc;
+  }
+#endif
+  MMB_UNI_LAUNCH(1)
+#undef MMB_UNI_LAUNCH
   return check_launch("mmb_fused_uni_generate");
 }
 
@@ -1743,16 +1826,9 @@ extern "C" int mmb_fused_epic_generate(int variant, int B, int N, const float* p
     // after the four-wave launch: the two write disjoint jets.  With the list of long jets (long_jets, n_long) it is
     // n_long workgroups; without (n_long < 0) every jet gets a workgroup that leaves at once when its jet is short --
     // but each of those needs an EMPTY CU to start (98 KB of LDS), which costs the four-wave launch ~15 ms.
-    struct Side { hipStream_t s = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; };
-    static Side sides[64];
-    int dev = 0;
-    MMB_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "mmb_fused_epic_generate: device index");
-    Side& sd = sides[dev];
-    if (sd.s == nullptr)
-      MMB_REQUIRE(hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) == hipSuccess &&
-                  hipEventCreateWithFlags(&sd.e0, hipEventDisableTiming) == hipSuccess &&
-                  hipEventCreateWithFlags(&sd.e1, hipEventDisableTiming) == hipSuccess,
-                  "mmb_fused_epic_generate: side stream");
+    SideStream* sdp = side_stream();
+    MMB_REQUIRE(sdp != nullptr, "mmb_fused_epic_generate: side stream");
+    SideStream& sd = *sdp;
     MMB_REQUIRE(hipEventRecord(sd.e0, as_stream(stream)) == hipSuccess && hipStreamWaitEvent(sd.s, sd.e0, 0) == hipSuccess,
                 "mmb_fused_epic_generate: fork of the side stream");
     rc = mmb_fused_epic_generate_w5(variant | 0x100, B, N, packed, desc, nb_branch, nb_branch1, nb_fused_exec, use_skip, off_cw,

@@ -102,7 +102,7 @@ SIGNATURES = {
                               c_i64p, c_f32p, C.c_int64, c_f32p, c_stream],
     "mmb_fused_uni_generate": [C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, c_f32p, c_i32p,
                                c_i64p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_float, C.c_int, C.c_float,
-                               c_f32p, C.c_uint64, C.c_uint64, c_i32p, c_stream],
+                               c_f32p, C.c_uint64, C.c_uint64, c_i32p, c_i32p, C.c_int, c_stream],
     "mmb_attention_fwd": [C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, C.c_int, c_f32p, C.c_int64,
                           c_f32p, c_stream],
     "mmb_attention_bwd": [C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, c_f32p, C.c_int, c_f32p, C.c_int64,

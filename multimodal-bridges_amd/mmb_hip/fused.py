@@ -759,10 +759,11 @@ def generate_uni(pack, mi, k, times, temb_steps, dt, thermo_kind, gamma, delta_n
     if ctab is None:
         ctab = time_vector_table(pack, temb_steps)
     n_ctab = ctab.shape[1]
+    lj, n_lj = long_jets(mi)
     call("mmb_fused_uni_generate", pack["variant"], B, N, f32(pack["packed"]), i32(pack["desc"]), pack["num_blocks"],
          pack["use_skip"], pack["off_table"], f32(mi.maskf), i32(mi.counts), i64(k, "k"), times.numel(),
          f32(times, "times"), f32(temb_steps, "temb_steps"), f32(ctab, "ctab"), n_ctab, _fl(dt), thermo_kind,
-         _fl(gamma), f32(delta_n, "delta_n"), seed, offset, i32(jet_schedule(mi)), stream())
+         _fl(gamma), f32(delta_n, "delta_n"), seed, offset, i32(jet_schedule(mi)), i32(lj), n_lj, stream())
 
 
 def algorithmic_flops_per_particle(model):

@@ -18,7 +18,9 @@ under torchrun (WORLD_SIZE set) it is one of the ranks and checks that WORLD_SIZ
 Extra objects on the line:
   roofline     -- the dominant kernel (the single-launch fused generation kernel: fp32 products formed from
                   six bf16 MFMA partial products), timed live with HIP events on the launch stream over extra
-                  profiled passes; peak = the guide's dense bf16 MFMA peak, frac = EXECUTED MFMA flops / peak
+                  profiled passes; peak = the guide's dense bf16 MFMA peak, frac = EXECUTED MFMA flops / peak --
+                  executed on the 32-particle tiles that hold a real particle only (roofline.working_tiles: half of
+                  them on AOJ multiplicities); algorithmic_* count every slot, as the reference computes them
   cpu_baseline -- the CPU oracle (op-for-op eager PyTorch restatement of the reference) timed
                   on the host cores over a bounded sample of the same workload (rank 0, N=1)
   training     -- training jets/s of the same model (fwd+bwd+all-reduce+clip+AdamW)

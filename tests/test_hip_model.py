@@ -830,3 +830,39 @@ def test_weight_gradients_over_real_rows_match_all_rows(golden, name, monkeypatc
         out["loss"].backward()
         res[rows_on] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
     grads_close(res["1"], res["0"], name, "fused_rows_vs_all_rows")
+
+
+@pytest.mark.parametrize("name", ["S3", "S2", "S3_n150"])
+def test_generation_does_not_depend_on_the_jet_schedule(golden, name, monkeypatch):
+    """jet_order = NULL (natural launch order) against the scheduled order (mmb_jet_schedule): a jet's result does not
+    depend on the workgroup that computes it or on its neighbours on the CU -- bit-identical, padded slots included."""
+    from tensorclass import TensorMultiModal
+    from datamodules.datasets import DataCoupling
+    from mmb_hip import fused
+    g = golden(name)
+    model = build(g, num_timesteps=5)
+    model.use_fused = True
+    N = g.t["mask"].shape[1]
+    uni = "xt" not in g.t
+    gen = torch.Generator().manual_seed(23)
+    B = 96
+    n = torch.randint(1, N + 1, (B,), generator=gen)
+    rank = torch.rand(B, N, generator=gen).argsort(dim=1).argsort(dim=1)
+    mask = (rank < n[:, None]).long().unsqueeze(-1)
+    k0 = torch.randint(0, 8, (B, N, 1), generator=gen) * mask
+    x0 = None if uni else torch.randn(B, N, 3, generator=gen) * mask
+
+    def run():
+        model.manual_seed(11)
+        src = TensorMultiModal(None, None if uni else x0.cuda(), k0.cuda(), mask.cuda())
+        state = TensorMultiModal(torch.zeros_like(src.mask), None if uni else src.continuous.clone(), src.discrete.clone(),
+                                 src.mask)
+        paths = model.simulate_dynamics(state, DataCoupling(src, TensorMultiModal(None, None, None, src.mask), None))
+        return (None if uni else paths.continuous[1].clone()), paths.discrete[1].clone()
+
+    xs, ks = run()
+    monkeypatch.setattr(fused, "jet_schedule", lambda mi: None)
+    xn, kn = run()
+    assert torch.equal(ks, kn)
+    if not uni:
+        assert torch.equal(xs, xn)

@@ -668,7 +668,10 @@ fused_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64_t* __
                      float* __restrict__ head_d) {
   __shared__ Lds L;
   __shared__ float4 S[DM::HFT * 4 * FE_THREADS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  __shared__ float padv[12];               // heads of the representative padded slot: drift 0..2, logits 4..11 (TilePlan)
+  __shared__ short order_s[32 * FE_WAVES];
+  const int lane = threadIdx.x & 63, wave = steer_wave((A.tiles & 2) != 0, threadIdx.x >> 6, lane, L.red);
+  const int tid = 64 * wave + lane, half = lane >> 5;
   load_constants<DM>(A, L, tid);
   __syncthreads();
   WRing<ring_depth_multi<DM>()> ring;
@@ -677,29 +680,53 @@ fused_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64_t* __
     __syncthreads();
     if (tid < DM::ET) L.temb[tid] = temb[(int64_t)b * temb_stride + tid];
     if (tid == 0) L.cnt = (float)A.counts[b];
-    const int p = 32 * wave + (lane & 31);
-    const bool valid = p < A.N;
+    const int slot = 32 * wave + (lane & 31);
+    const bool valid = slot < A.N;
+    const int p = jet_order((A.tiles & 1) != 0, A.maskf + (int64_t)b * A.N, A.N, slot, wave, lane, L.red, order_s);
     const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
     const float m = valid ? A.maskf[gp] : 0.0f;
     float xp[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int d = 0; d < DM::DC; ++d) xp[d] = valid ? x[gp * DM::DC + d] : 0.0f;
     const int kp = valid ? (int)k[gp] : 0;
+    // tiles without a real particle stay idle and take their heads from one representative padded slot, as in the
+    // generation loop (every slot of the result is what it was: the callers see padded slots too)
+    const TilePlan tp = plan_tiles((A.tiles & 1) != 0, true, m, valid, wave, lane, L.red);
     __syncthreads();
     f32x16 hc, hd;
     NoTrain nt;
-    forward_jet<DM, false>(A, L, S, xp, kp, m, which, hc, hd, tid, ring, nt);
+    float lg[DM::V];
+    float v3[3] = {0.0f, 0.0f, 0.0f};
+    if (tp.active) {
+      forward_jet<DM, false, true>(A, L, S, xp, kp, m, which, hc, hd, tid, ring, nt);
+      if (which != 1) { v3[0] = hc[0]; v3[1] = hc[1]; v3[2] = hc[2]; }
+      if (which != 0) gather_logits<DM>(hd, lg, lane);
+      if (tp.idle_any) {
+        if (tp.rep) {
+          if (which != 1) { padv[0] = v3[0]; padv[1] = v3[1]; padv[2] = v3[2]; }
+          if (which != 0) {
+#pragma unroll
+            for (int v = 0; v < DM::V; ++v) padv[4 + v] = lg[v];
+          }
+        }
+        __syncthreads();
+      }
+    } else {
+      forward_jet<DM, false, false>(A, L, S, xp, kp, m, which, hc, hd, tid, ring, nt);
+      if (tp.idle_any) {
+        __syncthreads();
+        v3[0] = padv[0]; v3[1] = padv[1]; v3[2] = padv[2];
+#pragma unroll
+        for (int v = 0; v < DM::V; ++v) lg[v] = padv[4 + v];
+      }
+    }
     if (valid && which != 1 && half == 0) {
 #pragma unroll
-      for (int d = 0; d < DM::DC; ++d) head_c[gp * DM::DC + d] = hc[d];       // features 0..2 = regs 0..2, half 0
+      for (int d = 0; d < DM::DC; ++d) head_c[gp * DM::DC + d] = v3[d];       // features 0..2 = regs 0..2, half 0
     }
-    if (valid && which != 0) {
-      float lg[DM::V];
-      gather_logits<DM>(hd, lg, lane);
-      if (half == 0) {
+    if (valid && which != 0 && half == 0) {
 #pragma unroll
-        for (int v = 0; v < DM::V; ++v) head_d[gp * DM::V + v] = lg[v];
-      }
+      for (int v = 0; v < DM::V; ++v) head_d[gp * DM::V + v] = lg[v];
     }
   }
 }
@@ -1067,7 +1094,10 @@ fused_uni_forward_kernel(FusedArgs A, const int64_t* __restrict__ k, const float
   __shared__ Lds L;
   __shared__ float4 S[DM::HT * 4 * FE_THREADS];
   __shared__ __attribute__((aligned(16))) float tab[DM::V * DM::EDP];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  __shared__ float padv[8];                // logits of the representative padded slot (TilePlan)
+  __shared__ short order_s[32 * FE_WAVES];
+  const int lane = threadIdx.x & 63, wave = steer_wave((A.tiles & 2) != 0, threadIdx.x >> 6, lane, L.red);
+  const int tid = 64 * wave + lane, half = lane >> 5;
   load_table_uni<DM>(A, tab, tid);
   load_desc(A, L, tid);
   __syncthreads();
@@ -1077,17 +1107,35 @@ fused_uni_forward_kernel(FusedArgs A, const int64_t* __restrict__ k, const float
     __syncthreads();
     if (tid < DM::ET) L.temb[tid] = temb[(int64_t)b * temb_stride + tid];
     if (tid == 0) L.cnt = (float)A.counts[b];
-    const int p = 32 * wave + (lane & 31);
-    const bool valid = p < A.N;
+    const int slot = 32 * wave + (lane & 31);
+    const bool valid = slot < A.N;
+    const int p = jet_order((A.tiles & 1) != 0, A.maskf + (int64_t)b * A.N, A.N, slot, wave, lane, L.red, order_s);
     const int64_t gp = (int64_t)b * A.N + (valid ? p : 0);
     const float m = valid ? A.maskf[gp] : 0.0f;
     const int kp = valid ? (int)k[gp] : 0;
+    const TilePlan tp = plan_tiles((A.tiles & 1) != 0, true, m, valid, wave, lane, L.red);      // (as fused_forward_kernel)
     __syncthreads();
     f32x16 hd;
     NoTrain nt;
-    forward_uni<DM, false>(A, L, S, tab, kp, m, hd, tid, ring, nt);
     float lg[8];
-    gather8(hd, lg, lane);
+    if (tp.active) {
+      forward_uni<DM, false, true>(A, L, S, tab, kp, m, hd, tid, ring, nt);
+      gather8(hd, lg, lane);
+      if (tp.idle_any) {
+        if (tp.rep) {
+#pragma unroll
+          for (int v = 0; v < 8; ++v) padv[v] = lg[v];
+        }
+        __syncthreads();
+      }
+    } else {
+      forward_uni<DM, false, false>(A, L, S, tab, kp, m, hd, tid, ring, nt);
+      if (tp.idle_any) {
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 8; ++v) lg[v] = padv[v];
+      }
+    }
     if (valid && half == 0) {
 #pragma unroll
       for (int v = 0; v < 8; ++v) head_d[gp * 8 + v] = lg[v];
@@ -1263,6 +1311,11 @@ static SideStream* side_stream() {
   return &sd;
 }
 #endif
+// MMB_FWD_TILES=<bits> (developer switch; default 3): the same two bits for the inference forward kernels
+static int fwd_tiles() {
+  const char* e = getenv("MMB_FWD_TILES");
+  return e ? atoi(e) : 3;
+}
 static int train_tiles() {
   const char* e = getenv("MMB_TRAIN_TILES");
   return e ? atoi(e) : 3;
@@ -1324,7 +1377,7 @@ extern "C" int mmb_fused_epic_forward(int variant, int B, int N, const float* pa
   if (which != 1) MMB_REQUIRE(head_c, "mmb_fused_epic_forward: head_c is NULL");
   if (which != 0) MMB_REQUIRE(head_d, "mmb_fused_epic_forward: head_d is NULL");
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), nb_branch, nb_fused_exec, use_skip, off_cw, off_cb,
-              off_table, B, N, maskf, counts, nb_branch1, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec)};
+              off_table, B, N, maskf, counts, nb_branch1, n_desc_multi(nb_branch, nb_branch1, nb_fused_exec), fwd_tiles()};
   const int grid = B < 4096 ? B : 4096;
   switch (variant) {
     case 0: hipLaunchKernelGGL(fused_forward_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, x, k, temb,
@@ -1391,7 +1444,7 @@ extern "C" int mmb_fused_uni_forward(int variant, int B, int N, const float* pac
   MMB_REQUIRE(variant >= 0 && variant < N_UNI_VARIANTS, "mmb_fused_uni_forward: unknown variant %d", variant);
   MMB_REQUIRE(k && temb && head_d, "mmb_fused_uni_forward: NULL state");
   FusedArgs A{nullptr, packed, reinterpret_cast<const LDesc*>(desc), num_blocks, 0, use_skip, 0, 0, off_table, B, N,
-              maskf, counts, 0, n_desc_uni(num_blocks)};
+              maskf, counts, 0, n_desc_uni(num_blocks), fwd_tiles()};
   const int grid = B < 4096 ? B : 4096;
   switch (variant) {
     case 0: hipLaunchKernelGGL(fused_uni_forward_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A, k, temb,

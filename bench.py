@@ -245,7 +245,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="S3", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=1024, help="jets per rank per step")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="jets per rank per step (0: 1024, the reference's batch_size; S5, whose driver shards a million jets "
+                         "in chunks of its own choosing: the chunk of configs/S5_large_generation.yaml, 8192)")
     ap.add_argument("--solver-steps", type=int, default=0, help="grid points (0: the workload's own: 100, S5: 200)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-jets", type=int, default=256)
@@ -299,7 +301,8 @@ def main():
     args.solver_steps = config.model.num_timesteps
     model.eval()
     model.manual_seed(0xA0A0, rank)
-    B = args.batch
+    B = args.batch or (int(config.data.batch_size) if args.workload == "S5" else 1024)
+    B_train = min(B, 1024)                                      # the training leg stays at the reference's batch size
 
     def barrier():
         if dist is not None:
@@ -357,7 +360,7 @@ def main():
     if not args.no_train:
         try:
             from pipeline.experiment import bench_training
-            training = bench_training(model, config, B, device, dist, steps=max(args.steps * 5, 10), warmup=10)
+            training = bench_training(model, config, B_train, device, dist, steps=max(args.steps * 5, 10), warmup=10)
         except Exception as exc:                                   # reported, never hidden
             if dist is not None:
                 # the other ranks are (or will be) inside a collective this rank never joins: leave at once with a
@@ -470,7 +473,7 @@ def main():
         }
         if training is not None:
             if "ms_per_step" in training:
-                training["roofline"] = training_roofline(model, config, args.workload, B, training)
+                training["roofline"] = training_roofline(model, config, args.workload, B_train, training)
             line["training"] = training
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, config, args.workload, args.cpu_jets, args.cpu_steps)

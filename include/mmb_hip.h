@@ -519,7 +519,11 @@ int mmb_fused_epic_train_forward(int variant, int B, int N, const float* packed,
  * sign words of l_out, fc_loc2 dZ, sign words of fc_loc1, fc_loc1 dZ, its column sums, g', fc_glob2 dZ, fc_glob1 out,
  * fc_glob1 dZ},
  * per branch the same followed by the projection {global.2 pre, dZ, global.0 pre, dZ, local.2 pre, dZ, local.0 pre,
- * dZ, column sums} and, for the continuous branch, d (continuous embedding) (rows,Ec). */
+ * dZ, column sums} and, for the continuous branch, d (continuous embedding) (rows,Ec).
+ * use_skip (this entry point and mmb_fused_uni_train_backward): bit 0 = the encoder-level skip connection; bit 1 =
+ * the caller reads the per-particle dZ slots at the rows of REAL particles only (weight gradients over the
+ * mmb_mask_rows list): tiles of 32 slots without a real particle then leave their rows of those slots unwritten
+ * (they would be zero rows; the continuous-embedding gradient keeps every row, its consumer reads them all). */
 int mmb_fused_epic_train_backward(int variant, int B, int N, const float* packed_bwd, const int32_t* desc_bwd,
                                   int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip,
                                   const float* maskf, const int32_t* counts,

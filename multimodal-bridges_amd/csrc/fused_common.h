@@ -242,6 +242,7 @@ struct Slots {
   const SaveSlot* tab;
   int n_slots, si;
   int b, N, p, half;
+  int dead = 0;               // 1: this lane's row accesses fall outside every buffer (stores dropped, loads read 0)
 
   __device__ __forceinline__ SaveSlot at(int i) const { return tab[i < n_slots ? i : n_slots - 1]; }
   __device__ __forceinline__ SaveSlot next() { return at(si++); }
@@ -254,7 +255,7 @@ struct Slots {
     room = room < 0 ? 0 : room;
     Rows r;
     r.R = __builtin_amdgcn_make_buffer_rsrc(s.p + base, 0, (int)(room * 4), 0x00020000);
-    r.vo = (p * (int)s.ld + 4 * half) * 4;
+    r.vo = dead ? 0x7FFF0000 : (p * (int)s.ld + 4 * half) * 4;
     return r;
   }
   __device__ __forceinline__ Rows rows() { return rows_of(next()); }

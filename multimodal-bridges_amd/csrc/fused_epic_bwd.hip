@@ -50,7 +50,8 @@ struct BwdArgs {
   float drop_p;
   uint64_t seed, offset0;
   int nb_branch1;
-  int tiles;               // bit 0 idle tiles of padded slots, bit 1 tile-to-SIMD steering: as the forward ran (TilePlan)
+  int tiles;               // bit 0 idle tiles of padded slots, bit 1 tile-to-SIMD steering: as the forward ran (TilePlan);
+                           // bit 3: idle tiles leave their dZ rows unwritten (nobody reads them: bwd_tiles)
   const int32_t* jet_order;  // (B) launch order of the jets (mmb_jet_schedule) or NULL
 };
 
@@ -150,7 +151,10 @@ struct EpicB {
     const BDesc g1 = D[0], g2 = D[1], l1 = D[2], l2 = D[3];
     const bool dr = drop_p > 0.0f;
     // An idle tile (padded slots only: every gradient row is exactly zero) keeps the slot walk, the barriers and its
-    // share of the per-jet matvecs, stores its zero dZ rows for the weight-gradient kernels and skips the rest.
+    // share of the per-jet matvecs, stores its zero dZ rows for the weight-gradient kernels and skips the rest.  When
+    // the caller's weight-gradient launches reduce over the rows of real particles only (bit 3 of A.tiles, set from
+    // bit 1 of the entry points' use_skip), nobody reads those rows: sl.dead puts the tile's row accesses outside
+    // every buffer, the stores are dropped by the bounds check (reverse kernel 0.90 -> 0.77 ms at B = 1024).
     // ---- l_out = drop(lrelu(y1)) + skip ;  y1 = x + W2 lh + b2
     const uint64_t sgn_y1 = sl.bits(tid);
     const Rows r_dz2 = sl.rows();
@@ -278,7 +282,10 @@ struct EpicB {
       f32x16 din[1];
       zero_tiles<1>(din);
       if (act) mma_go<HT, 1>(din, [&](auto fc) -> const f32x16& { return dh[decltype(fc)::v]; }, P, p0.a, lane);
+      const int dd = sl.dead;                            // d_in goes to the embedding's reverse pass, which reads every
+      sl.dead = 0;                                       // row: an idle tile keeps writing its zero rows here
       const Rows r = sl.rows();                          // (rows, EIN): only the column groups below EIN exist
+      sl.dead = dd;
       ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;
         if (8 * q + 4 * half < EIN) {
           const float4 v = make_float4(din[0][4 * q], din[0][4 * q + 1], din[0][4 * q + 2], din[0][4 * q + 3]);
@@ -320,6 +327,7 @@ fused_train_backward_kernel(BwdArgs A) {
     if (tid < 128) LB.dtemb[tid] = 0.0f;
     __syncthreads();
     Slots sl{A.slots, A.n_slots, 4, b, A.N, p, half};
+    sl.dead = (A.tiles & 8) != 0 && !act;
     const SaveSlot s_df = sl.at(0), s_dhb = sl.at(1), s_dboth = sl.at(2), s_dtemb = sl.at(3);
     // ---- heads: o = W2 h + b, h = gelu(W0 [m temb, f_i, h_i] + b)
     ffor<2>([&](auto hc) {
@@ -456,6 +464,7 @@ fused_uni_train_backward_kernel(BwdArgs A) {
     if (tid < 128) LB.dtemb[tid] = 0.0f;
     __syncthreads();
     Slots sl{A.slots, A.n_slots, 1, b, A.N, p, half};
+    sl.dead = (A.tiles & 8) != 0 && !act;
     const SaveSlot s_dtemb = sl.at(0);
     const SaveSlot sd = sl.next();
     f32x16 dx[HT];
@@ -490,6 +499,14 @@ static int train_tiles() {
   const char* e = getenv("MMB_TRAIN_TILES");
   return e ? atoi(e) : 3;
 }
+// use_skip of the two entry points: bit 0 the encoder-level skip connection, bit 1 "the dZ rows of padded slots are
+// never read" (the caller reduces its weight gradients over mmb_mask_rows lists) -> bit 3 of the kernels' tile plan
+static int bwd_tiles(int& use_skip) {
+  int tiles = train_tiles();
+  if ((use_skip & 2) && (tiles & 1)) tiles |= 8;
+  use_skip &= 1;
+  return tiles;
+}
 
 }  // namespace mmb
 
@@ -519,8 +536,9 @@ extern "C" int mmb_fused_uni_train_backward(int variant, int B, int N, const flo
   const int expect = 1 + 2 + num_blocks * 9 + 9;
   MMB_REQUIRE(n_slots == expect, "mmb_fused_uni_train_backward: %d slots given, the architecture has %d", n_slots,
               expect);
+  const int tiles = bwd_tiles(use_skip);
   BwdArgs A{packed_bwd, reinterpret_cast<const BDesc*>(desc_bwd), num_blocks, 0, use_skip, B, N, maskf,
-            counts, reinterpret_cast<const SaveSlot*>(slots), n_slots, drop_p, seed, offset0, 0, train_tiles(), jet_order};
+            counts, reinterpret_cast<const SaveSlot*>(slots), n_slots, drop_p, seed, offset0, 0, tiles, jet_order};
   const int grid = B < 4096 ? B : 4096;
   switch (variant) {
     case 0: hipLaunchKernelGGL(fused_uni_train_backward_kernel<UniS2>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A); break;
@@ -549,8 +567,9 @@ extern "C" int mmb_fused_epic_train_backward(int variant, int B, int N, const fl
   const int expect = 4 + 8 + (1 + nb_fused_exec * per_layer) + 2 * (1 + 9) + (nb_branch + nb_branch1) * per_layer + 1;
   MMB_REQUIRE(n_slots == expect, "mmb_fused_epic_train_backward: %d slots given, the architecture has %d", n_slots,
               expect);
+  const int tiles = bwd_tiles(use_skip);
   BwdArgs A{packed_bwd, reinterpret_cast<const BDesc*>(desc_bwd), nb_branch, nb_fused_exec, use_skip, B, N, maskf,
-            counts, reinterpret_cast<const SaveSlot*>(slots), n_slots, drop_p, seed, offset0, nb_branch1, train_tiles(), jet_order};
+            counts, reinterpret_cast<const SaveSlot*>(slots), n_slots, drop_p, seed, offset0, nb_branch1, tiles, jet_order};
   const int grid = B < 4096 ? B : 4096;
   switch (variant) {
     case 0: hipLaunchKernelGGL(fused_train_backward_kernel<DimsS3>, dim3(grid), dim3(FE_THREADS), 0, as_stream(stream), A); break;

@@ -383,6 +383,12 @@ class Workspace:
                 recs.append(rec)
                 nblk += n
             self.gw.append((cls, torch.tensor(recs, dtype=torch.int64).to(dev), len(recs), nblk))
+        # When every reader of the kernel-written per-particle dZ slots goes through the row list, the reverse kernel's
+        # idle tiles (padded slots only) need not store their zero rows (MMB_BWD_DEAD_ROWS=0: developer switch).  The
+        # head gradients come from the loss kernel, which writes every row; a generic launch reads every row of its Z.
+        outside = {t.data_ptr() for t in d_heads}
+        self.real_rows_only = (self.use_rows and M > B and os.environ.get("MMB_BWD_DEAD_ROWS", "1") != "0"
+                               and all(q[1].shape[0] != M or q[1].data_ptr() in outside for q in self.generic))
         self.pack = pack
         self.grad_ptrs = None
         self.own_grads = None
@@ -467,7 +473,8 @@ class Workspace:
         pack = self.pack
         pbwd = fused_epic.packed_bwd(pack, fused_epic.params_version(model))
         bp = self.bp
-        fused_epic.train_backward(pack, pbwd, st.mi, bp["table"], bp["n"], st.drop_p, st.seed, st.offset0)
+        fused_epic.train_backward(pack, pbwd, st.mi, bp["table"], bp["n"], st.drop_p, st.seed, st.offset0,
+                                  real_rows_only=self.real_rows_only)
         self.arena.zero_()
         if self.use_rows:
             ops.mask_rows(st.mi, self.rows)

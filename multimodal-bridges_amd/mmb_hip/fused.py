@@ -674,16 +674,19 @@ def train_forward_uni(pack, mi, k, temb, slots, n_slots, drop_p, seed, offset0, 
     return hd
 
 
-def train_backward(pack, pbwd, mi, slots, n_slots, drop_p, seed, offset0):
+def train_backward(pack, pbwd, mi, slots, n_slots, drop_p, seed, offset0, real_rows_only=False):
     """Reverse pass of the whole encoder for every jet in one launch (csrc/fused_epic_bwd.hip): fills the dZ / column-sum
-    slots the weight-gradient kernel consumes.  slots: device int64 (n_slots, 3)."""
+    slots the weight-gradient kernel consumes.  slots: device int64 (n_slots, 3).  real_rows_only: the caller reads
+    the per-particle dZ slots at the rows of real particles only (mmb_mask_rows lists) -- tiles of padded slots then
+    leave their rows UNWRITTEN (bit 1 of the entry points' use_skip); the continuous-input gradient keeps every row."""
+    skip = int(pack["use_skip"]) | (2 if real_rows_only else 0)
     if pack["kind"] == "uni":
         call("mmb_fused_uni_train_backward", pack["variant"], mi.B, mi.N, f32(pbwd), i32(pack["desc_bwd"]),
-             pack["num_blocks"], pack["use_skip"], f32(mi.maskf), i32(mi.counts), C.c_void_p(slots.data_ptr()), n_slots,
+             pack["num_blocks"], skip, f32(mi.maskf), i32(mi.counts), C.c_void_p(slots.data_ptr()), n_slots,
              _fl(drop_p), seed, offset0, i32(jet_schedule(mi)), stream())
         return
     call("mmb_fused_epic_train_backward", pack["variant"], mi.B, mi.N, f32(pbwd), i32(pack["desc_bwd"]), pack["nb_branch"],
-         pack["nb_branch1"], pack["nb_fused_exec"], pack["use_skip"], f32(mi.maskf), i32(mi.counts),
+         pack["nb_branch1"], pack["nb_fused_exec"], skip, f32(mi.maskf), i32(mi.counts),
          C.c_void_p(slots.data_ptr()), n_slots,
          _fl(drop_p), seed, offset0, i32(jet_schedule(mi)), stream())
 

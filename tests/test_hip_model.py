@@ -833,6 +833,57 @@ def test_weight_gradients_over_real_rows_match_all_rows(golden, name, monkeypatc
 
 
 @pytest.mark.parametrize("name", ["S3", "S2", "S3_n150"])
+def test_unwritten_rows_of_idle_tiles_leave_no_trace(golden, name, monkeypatch):
+    """With the weight gradients reduced over the rows of real particles, the reverse kernel's idle tiles leave their rows
+    of the per-particle dZ slots UNWRITTEN (bit 1 of use_skip): whatever an earlier step with other masks left there
+    must never be read.  Step A, step B (the masks of A in reverse jet order: other real rows, non-zero gradients in
+    rows that A pads), step A again on the same persistent workspace -> the gradients of A, to the rounding of the
+    atomics; and the same against the build that writes every row (MMB_BWD_DEAD_ROWS=0)."""
+    from tensorclass import TensorMultiModal
+    from datamodules.datasets import DataCoupling
+    from conftest import GRAD_TOL_RERUN
+    g = golden(name)
+    N = g.t["mask"].shape[1]
+    uni = "xt" not in g.t
+    gen = torch.Generator().manual_seed(41)
+    B = 96
+    n = torch.randint(1, N + 1, (B,), generator=gen)
+    n[:8] = torch.tensor([1, 31, 32, 33, 64, 96, N - 1, N])
+    rank = torch.rand(B, N, generator=gen).argsort(dim=1).argsort(dim=1)
+    mask = (rank < n[:, None]).long().unsqueeze(-1).cuda()
+    rnd = lambda *s: torch.randn(*s, generator=gen).cuda()
+    ri = lambda *s: torch.randint(0, 8, s, generator=gen).cuda()
+    xt, x1, kt, k1 = rnd(B, N, 3), rnd(B, N, 3), ri(B, N, 1), ri(B, N, 1)
+    t = (torch.rand(B, generator=gen) * 0.98 + 0.01).cuda().reshape(B, 1, 1)
+
+    def run(dead):
+        monkeypatch.setenv("MMB_BWD_DEAD_ROWS", dead)
+        model = build(g).train()
+        model.use_fused_training = model.use_fused_backward = True
+
+        def step(flip):
+            f = (lambda a: a.flip(0)) if flip else (lambda a: a)
+            m = f(mask)
+            model.manual_seed(7)
+            st = TensorMultiModal(f(t), None if uni else f(xt) * m, f(kt) * m, m)
+            tgt = TensorMultiModal(None, None if uni else f(x1) * m, f(k1) * m, m)
+            src = TensorMultiModal(None, None if uni else torch.zeros_like(xt), torch.zeros_like(kt), torch.ones_like(m))
+            out = model.step_from_state(st, DataCoupling(src, tgt, None), "train", True)
+            model.zero_grad(set_to_none=True)
+            out["loss"].backward()
+            return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+        a = step(False)
+        step(True)
+        return a, step(False)
+
+    a1, a1_again = run("1")
+    grads_close(a1_again, a1, name, "dead_rows_rerun", tol=GRAD_TOL_RERUN)
+    a0, _ = run("0")
+    grads_close(a1, a0, name, "dead_rows_vs_written_rows", tol=GRAD_TOL_RERUN)
+
+
+@pytest.mark.parametrize("name", ["S3", "S2", "S3_n150"])
 def test_generation_does_not_depend_on_the_jet_schedule(golden, name, monkeypatch):
     """jet_order = NULL (natural launch order) against the scheduled order (mmb_jet_schedule): a jet's result does not
     depend on the workgroup that computes it or on its neighbours on the CU -- bit-identical, padded slots included."""

@@ -522,8 +522,8 @@ int mmb_fused_epic_train_forward(int variant, int B, int N, const float* packed,
  * dZ, column sums} and, for the continuous branch, d (continuous embedding) (rows,Ec).
  * use_skip (this entry point and mmb_fused_uni_train_backward): bit 0 = the encoder-level skip connection; bit 1 =
  * the caller reads the per-particle dZ slots at the rows of REAL particles only (weight gradients over the
- * mmb_mask_rows list): tiles of 32 slots without a real particle then leave their rows of those slots unwritten
- * (they would be zero rows; the continuous-embedding gradient keeps every row, its consumer reads them all). */
+ * mmb_mask_rows list): padded slots then leave their rows of those slots unwritten (they would be zero rows; the
+ * continuous-embedding gradient keeps every row, its consumer reads them all). */
 int mmb_fused_epic_train_backward(int variant, int B, int N, const float* packed_bwd, const int32_t* desc_bwd,
                                   int nb_branch, int nb_branch1, int nb_fused_exec, int use_skip,
                                   const float* maskf, const int32_t* counts,

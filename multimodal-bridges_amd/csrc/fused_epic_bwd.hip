@@ -51,7 +51,8 @@ struct BwdArgs {
   uint64_t seed, offset0;
   int nb_branch1;
   int tiles;               // bit 0 idle tiles of padded slots, bit 1 tile-to-SIMD steering: as the forward ran (TilePlan);
-                           // bit 3: idle tiles leave their dZ rows unwritten (nobody reads them: bwd_tiles)
+                           // bit 3: idle tiles leave their dZ rows unwritten (nobody reads them: bwd_tiles),
+                           // bit 4: so do the padded lanes of working tiles
   const int32_t* jet_order;  // (B) launch order of the jets (mmb_jet_schedule) or NULL
 };
 
@@ -327,7 +328,7 @@ fused_train_backward_kernel(BwdArgs A) {
     if (tid < 128) LB.dtemb[tid] = 0.0f;
     __syncthreads();
     Slots sl{A.slots, A.n_slots, 4, b, A.N, p, half};
-    sl.dead = (A.tiles & 8) != 0 && !act;
+    sl.dead = (A.tiles & 8) != 0 && (!act || ((A.tiles & 16) != 0 && m == 0.0f));
     const SaveSlot s_df = sl.at(0), s_dhb = sl.at(1), s_dboth = sl.at(2), s_dtemb = sl.at(3);
     // ---- heads: o = W2 h + b, h = gelu(W0 [m temb, f_i, h_i] + b)
     ffor<2>([&](auto hc) {
@@ -464,7 +465,7 @@ fused_uni_train_backward_kernel(BwdArgs A) {
     if (tid < 128) LB.dtemb[tid] = 0.0f;
     __syncthreads();
     Slots sl{A.slots, A.n_slots, 1, b, A.N, p, half};
-    sl.dead = (A.tiles & 8) != 0 && !act;
+    sl.dead = (A.tiles & 8) != 0 && (!act || ((A.tiles & 16) != 0 && m == 0.0f));
     const SaveSlot s_dtemb = sl.at(0);
     const SaveSlot sd = sl.next();
     f32x16 dx[HT];
@@ -503,7 +504,11 @@ static int train_tiles() {
 // never read" (the caller reduces its weight gradients over mmb_mask_rows lists) -> bit 3 of the kernels' tile plan
 static int bwd_tiles(int& use_skip) {
   int tiles = train_tiles();
-  if ((use_skip & 2) && (tiles & 1)) tiles |= 8;
+  if ((use_skip & 2) && (tiles & 1)) {
+    tiles |= 8;
+    const char* e = getenv("MMB_BWD_DEAD_LANES");          // padded lanes of working tiles too (developer switch: 0 = off)
+    if (!e || atoi(e) != 0) tiles |= 16;
+  }
   use_skip &= 1;
   return tiles;
 }

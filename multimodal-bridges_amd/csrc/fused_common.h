@@ -165,6 +165,7 @@ struct Train {
   int b, N, p;               // jet, particles per jet, this lane's particle
   float drop_p;
   uint64_t seed, off;
+  int dead = 0;              // 1: a padded slot -- its rows of the tape are never read, the stores go beyond the buffer
 
   __device__ __forceinline__ SaveSlot next() {
     const int i = si < n_slots ? si : n_slots - 1;
@@ -185,7 +186,7 @@ struct Train {
     room = room < want ? room : want;
     room = room < 0 ? 0 : room;
     const __amdgpu_buffer_rsrc_t R = __builtin_amdgcn_make_buffer_rsrc(s.p + base, 0, (int)(room * 4), 0x00020000);
-    const int vo = (p * (int)s.ld + 4 * half) * 4;
+    const int vo = dead ? 0x7FFF0000 : (p * (int)s.ld + 4 * half) * 4;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     ffor<HT>([&](auto tc) { constexpr int t = decltype(tc)::v;
       ffor<4>([&](auto qc) { constexpr int q = decltype(qc)::v;

@@ -766,6 +766,7 @@ fused_train_forward_kernel(FusedArgs A, const float* __restrict__ x, const int64
     const TilePlan tp = plan_tiles((A.tiles & 1) != 0, false, m, valid, wave, lane, L.red);
     __syncthreads();
     Train tr{slots, n_slots, 0, b, A.N, p, drop_p, seed, offset0};      // rows and dropout keys by the true slot
+    tr.dead = (A.tiles & 16) != 0 && m == 0.0f;        // padded slots of working tiles: like the idle tiles' rows, unwritten
     f32x16 hc, hd;
     if (tp.active) forward_jet<DM, false, true>(A, L, S, xp, kp, m, 2, hc, hd, tid, ring, tr);
     else forward_jet<DM, false, false>(A, L, S, xp, kp, m, 2, hc, hd, tid, ring, tr);
@@ -1175,6 +1176,7 @@ fused_uni_train_forward_kernel(FusedArgs A, const int64_t* __restrict__ k, const
     const TilePlan tp = plan_tiles((A.tiles & 1) != 0, false, m, valid, wave, lane, L.red);
     __syncthreads();
     Train tr{slots, n_slots, 0, b, A.N, p, drop_p, seed, offset0};      // rows and dropout keys by the true slot
+    tr.dead = (A.tiles & 16) != 0 && m == 0.0f;        // padded slots of working tiles: like the idle tiles' rows, unwritten
     f32x16 hd;
     if (tp.active) forward_uni<DM, false, true>(A, L, S, tab, kp, m, hd, tid, ring, tr);
     else forward_uni<DM, false, false>(A, L, S, tab, kp, m, hd, tid, ring, tr);
@@ -1318,7 +1320,12 @@ static int fwd_tiles() {
 }
 static int train_tiles() {
   const char* e = getenv("MMB_TRAIN_TILES");
-  return e ? atoi(e) : 3;
+  int tiles = e ? atoi(e) : 3;
+  // bit 4: the padded slots of WORKING tiles leave their tape rows unwritten too (the idle tiles' contract, per lane:
+  // nothing multiplies those rows by anything but exact zeros; MMB_FWD_DEAD_LANES=0: developer switch)
+  const char* d = getenv("MMB_FWD_DEAD_LANES");
+  if ((tiles & 1) && (!d || atoi(d) != 0)) tiles |= 16;
+  return tiles;
 }
 static int check_fused(const char* name, int B, int N, const void* P, const void* D, const void* maskf,
                        const void* counts, int n_desc) {

@@ -38,8 +38,8 @@ class _Plan:
         return t
 
     def rows(self, width):                       # one row per particle
-        # zeros, not empty: the kernels leave the rows of idle tiles (padded slots only) unwritten, and the weight-gradient
-        # GEMMs multiply them by gradient rows that are exactly zero -- whatever is there must be finite
+        # zeros, not empty: the kernels leave the rows of padded slots unwritten (whole idle tiles and the padded slots
+        # of working tiles); whoever reads them multiplies by gradient rows that are exactly zero -- they must be finite
         return self.slot(torch.zeros(self.M, width, dtype=torch.float32, device=self.dev))
 
     def jets(self, width):                       # one row per jet
